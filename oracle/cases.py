@@ -1,0 +1,118 @@
+"""Synthetic inputs of the BASELINE.json configs  --  TEST INFRASTRUCTURE ONLY.
+
+Pure NumPy (plus the oracle's own signal helpers); no reference code is needed to rebuild an
+input, so the same inputs exist on the GPU box.  ``make_golden.py`` feeds them to the imported
+reference in the build container; tests feed them to the oracle and to the HIP engine.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import pal_oracle as O
+
+DEFAULT_PLANES = [                                   # values of main.py:41-43
+    {"plane": [1, 0, 0, -5], "material": "wood"},
+    {"plane": [0, 1, 0, -5], "material": "metal"},
+    {"plane": [0, 0, 1, -5], "material": "wood"},
+]
+LOW_LOSS = {
+    "air": {"absorption": 0.01, "freq": 0.0},
+    "wood": {"absorption": 0.05, "freq": 1e-6},
+    "metal": {"absorption": 0.1, "freq": 1e-6},
+}
+C_SOUND = O.speed_of_sound(20, 50)                   # 343.62 m/s
+
+
+def c1_config() -> dict:
+    """Values of the reference's module-level ``config`` (main.py:26-64), analysis/plots off."""
+    return {
+        "fs": 44100, "duration": 1.0, "celsius": 20, "humidity": 50,
+        "mic_positions": [[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]],
+        "source_position": [0.5, 0.5, 0.5], "signal_type": "sine", "freq": 1000,
+        "reflective_planes": [dict(p) for p in DEFAULT_PLANES],
+        "calibration": {"signal_type": "chirp", "freq_start": 500, "freq_end": 5000,
+                        "attenuation_factor": 1.0, "noise_level": 0.01},
+        "localization": {"max_reflections": 3, "filter_method": "butterworth", "absorption_threshold": 0.01,
+                         "analyze_correlation": False, "visualize_correlation": False,
+                         "clustering_method": "kmeans", "clustering_eps": 0.001, "clustering_min_samples": 2,
+                         "max_expected_delay": 0.05},
+    }
+
+
+def c2_config() -> dict:
+    cfg = c1_config()
+    cfg.update({"fs": 48000, "mic_positions": np.random.default_rng(2).uniform(-0.5, 0.5, (8, 3)).tolist(),
+                "source_position": [1.0, 2.0, 0.5], "signal_type": "chirp", "freq": 500})
+    return cfg
+
+
+def grid_array_64() -> np.ndarray:
+    ax = (np.arange(8) - 3.5) * 0.1
+    gx, gy = np.meshgrid(ax, ax, indexing="ij")
+    return np.stack([gx.ravel(), gy.ravel(), np.zeros(64)], axis=1)
+
+
+def c3_sources() -> np.ndarray:
+    return np.random.default_rng(3).uniform([-3, -3, 0.5], [3, 3, 3], (16, 3))
+
+
+def c3_base(trial: int) -> np.ndarray:
+    return np.random.default_rng(100 + trial).standard_normal(24000)
+
+
+def c3_config(trial: int) -> dict:
+    cfg = c1_config()
+    cfg.update({"fs": 48000, "duration": 0.5, "mic_positions": grid_array_64().tolist(),
+                "source_position": c3_sources()[trial].tolist(), "signal_type": "noise", "freq": 1000,
+                "reflective_planes": []})
+    return cfg
+
+
+def fibonacci_sphere(count: int, radius: float) -> np.ndarray:
+    i = np.arange(count) + 0.5
+    phi = np.arccos(1 - 2 * i / count)
+    theta = np.pi * (1 + 5 ** 0.5) * i
+    return radius * np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], axis=1)
+
+
+def c4_frames(mics: int = 256) -> np.ndarray:
+    """First ``mics`` microphones of C4: delayed chirp 500->2500 Hz + white noise at -20 dB, 96 kHz, 1 s."""
+    fs, n = 96000, 96000
+    pos = fibonacci_sphere(256, 0.5)[:mics]
+    chirp = O.generate_signal("chirp", fs, 1.0, 500)
+    noise = np.random.default_rng(4)
+    out = np.empty((mics, n))
+    for m in range(mics):
+        d = np.linalg.norm(np.array([2.0, 1.0, 0.5]) - pos[m])
+        out[m] = O.fractional_delay(chirp, d / C_SOUND, fs) + 0.1 * noise.standard_normal(n)
+    return out
+
+
+def c5_source(frame: int) -> np.ndarray:
+    steps = np.random.default_rng(5).normal(0.0, 0.02, (1024, 3))
+    return np.array([1.0, 2.0, 0.5]) + steps[: frame + 1].sum(axis=0)
+
+
+def c5_base(frame: int) -> np.ndarray:
+    return np.random.default_rng(1000 + frame).standard_normal(12000)
+
+
+def metric_frames(batch: int, mics: int = 64, n: int = 44100, first: int = 0) -> np.ndarray:
+    """Frames of the metric run: independent noise per mic plus one common component with an integer
+    per-mic delay.  Frame ``b`` depends only on ``b`` so shards of a batch can be built per rank."""
+    delays = np.random.default_rng(8).integers(-60, 60, size=64)[:mics]
+    out = np.empty((batch, mics, n))
+    for b in range(batch):
+        g = np.random.default_rng([7, first + b])
+        common = g.standard_normal(n + 200)
+        out[b] = g.standard_normal((mics, n))
+        for m in range(mics):
+            out[b, m] += common[100 + delays[m]: 100 + delays[m] + n]
+    return out
+
+
+def waveform_digest(x: np.ndarray) -> np.ndarray:
+    """Small fingerprint of a waveform: length, sum, sum of squares, max |x| and 64 strided samples."""
+    x = np.asarray(x, dtype=np.float64)
+    idx = np.linspace(0, x.shape[0] - 1, 64).astype(np.int64)
+    return np.concatenate(([x.shape[0], x.sum(), (x * x).sum(), np.abs(x).max()], x[idx]))

@@ -1,0 +1,254 @@
+"""Golden-vector generator  --  runs ONLY in the build container (needs /root/reference).
+
+Imports the unmodified reference modules, feeds them the synthetic inputs of ``oracle/cases.py``
+and writes KB-scale ``tests/golden/*.npz`` fixtures (inputs are rebuilt from seeds by the tests,
+only the reference's OUTPUTS are stored).  Nothing here travels to the GPU box as a dependency.
+
+``soundfile`` and ``resampy`` are not installed in this image and are imported at the top of the
+reference's ``utils.py:8`` / ``signal_processing.py:8``; they are used only by ``read_audio_files``
+and ``resample_audio`` (out of scope, never called here), so two EMPTY module objects are
+registered under those names to let the import statements pass.
+
+    cd /tmp && MPLBACKEND=Agg python /root/repo/oracle/make_golden.py
+"""
+from __future__ import annotations
+
+import logging
+import os
+import sys
+import tempfile
+import time
+import types
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+for _name in ("soundfile", "resampy"):
+    sys.modules.setdefault(_name, types.ModuleType(_name))
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import scipy  # noqa: E402
+import sklearn  # noqa: E402
+
+import main as ref_main  # noqa: E402
+import signal_processing as ref_sp  # noqa: E402
+import utils as ref_utils  # noqa: E402
+
+from oracle import cases  # noqa: E402
+
+logging.disable(logging.CRITICAL)
+OUT = os.path.join(REPO, "tests", "golden")
+META = np.array([f"numpy {np.__version__}", f"scipy {scipy.__version__}", f"sklearn {sklearn.__version__}",
+                 "reference zeynelacikgoez/PyAudioLocalization @ 2025-08-01"])
+
+
+def pair_table(filtered, fs, med):
+    """Reference pair loop (main.py:202-228) -> per-pair records."""
+    m = len(filtered)
+    n2 = len(filtered[0])
+    rec = {k: [] for k in ("k_sel", "k_argmax", "cmax", "cmin", "snr", "ptp", "td")}
+    for i in range(m):
+        for j in range(i + 1, m):
+            td, corr, lags = ref_utils.get_time_delays_phat(filtered[i], filtered[j], fs, num_peaks=1,
+                                                            max_expected_delay=med)
+            rec["td"].append(td[0])
+            rec["k_sel"].append(int(round(td[0] * fs)) + n2 - 1)
+            rec["k_argmax"].append(int(np.argmax(corr)))
+            rec["cmax"].append(np.max(corr))
+            rec["cmin"].append(np.min(corr))
+            rec["snr"].append(ref_utils.compute_snr(corr))
+            rec["ptp"].append(ref_utils.compute_peak_to_peak_ratio(corr))
+    out = {k: np.array(v, dtype=np.float64) for k, v in rec.items()}
+    out["k_sel"] = out["k_sel"].astype(np.int32)
+    out["k_argmax"] = out["k_argmax"].astype(np.int32)
+    return out
+
+
+def stage_outputs(signals, fs, meds, prefix=""):
+    """sync -> filter -> pairs with the reference's functions (main.py:188-228)."""
+    synced = ref_utils.synchronize_signals_improved(signals, fs)
+    filt = [ref_sp.noise_reduction(s, fs, method="butterworth") for s in synced]
+    out = {prefix + "L": np.array([len(filt[0])]),
+           prefix + "sync_digest": np.array([cases.waveform_digest(s) for s in synced]),
+           prefix + "filt_digest": np.array([cases.waveform_digest(s) for s in filt])}
+    for med in meds:
+        tag = "none" if med is None else ("%g" % med).replace(".", "p")
+        for k, v in pair_table(filt, fs, med).items():
+            out[f"{prefix}{k}_{tag}"] = v
+    return out
+
+
+def run_localize(cfg, materials=None, base=None):
+    """localize_sound_source in a scratch dir (it writes PNGs)."""
+    keep_mat, keep_gen = ref_main.material_properties, ref_sp.generate_signal
+    cwd = os.getcwd()
+    try:
+        if materials is not None:
+            ref_main.material_properties = materials
+        if base is not None:
+            ref_sp.generate_signal = lambda *a, **k: base.copy()
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            res = ref_main.localize_sound_source(cfg, use_simulation=True, show_plots=False)
+            os.chdir(cwd)
+        return np.asarray(res["estimated_position"], dtype=np.float64)
+    finally:
+        os.chdir(cwd)
+        ref_main.material_properties, ref_sp.generate_signal = keep_mat, keep_gen
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name), meta=META, **arrays)
+    print(f"  wrote {name}: {sum(np.asarray(v).nbytes for v in arrays.values())} B raw", flush=True)
+
+
+def golden_c1():
+    cfg = cases.c1_config()
+    sig = ref_main.simulate_signals_with_multipath(cfg["source_position"], np.array(cfg["mic_positions"]), cfg["fs"],
+                                                   cases.C_SOUND, 1.0, "sine", 1000, cfg["reflective_planes"],
+                                                   ref_main.material_properties, 3, 0.01)
+    out = stage_outputs(sig, cfg["fs"], (0.05, None))
+    out["sim_digest"] = np.array([cases.waveform_digest(s) for s in sig])
+    out["position"] = run_localize(cfg)
+    save("c1_example1.npz", **out)
+
+
+def golden_c2():
+    cfg = cases.c2_config()
+    mics = np.array(cfg["mic_positions"])
+    out = {}
+    for tag, table in (("a_", ref_main.material_properties), ("b_", cases.LOW_LOSS)):
+        imgs = ref_utils.generate_image_sources_iterative(cfg["source_position"], cfg["reflective_planes"], 3, 500,
+                                                          table, mics, 0.01)
+        out[tag + "images"] = np.array([i["source"] for i in imgs]).reshape(-1, 3)
+        out[tag + "image_materials"] = np.array([i["material"] for i in imgs], dtype="U8")
+        sig = ref_main.simulate_signals_with_multipath(cfg["source_position"], mics, 48000, cases.C_SOUND, 1.0,
+                                                       "chirp", 500, cfg["reflective_planes"], table, 3, 0.01)
+        out[tag + "sim_digest"] = np.array([cases.waveform_digest(s) for s in sig])
+        out.update(stage_outputs(sig, 48000, (0.05, None), prefix=tag))
+        out[tag + "position"] = run_localize(cfg, materials=table)
+    save("c2_chirp8.npz", **out)
+
+
+def golden_c3(trial=0):
+    cfg = cases.c3_config(trial)
+    base = cases.c3_base(trial)
+    keep = ref_sp.generate_signal
+    try:
+        ref_sp.generate_signal = lambda *a, **k: base.copy()
+        sig = ref_main.simulate_signals_with_multipath(cfg["source_position"], np.array(cfg["mic_positions"]), 48000,
+                                                       cases.C_SOUND, 0.5, "noise", 1000, [],
+                                                       ref_main.material_properties, 3, 0.01)
+    finally:
+        ref_sp.generate_signal = keep
+    out = stage_outputs(sig, 48000, (0.05, None))
+    out["sim_digest"] = np.array([cases.waveform_digest(s) for s in sig])
+    out["position"] = run_localize(cfg, base=base)
+    save(f"c3_grid64_trial{trial}.npz", **out)
+
+
+def golden_c4(mics=12):
+    frames = cases.c4_frames(mics)
+    out = {"frames_digest": np.array([cases.waveform_digest(s) for s in frames])}
+    for med in (0.05, None):
+        tag = "none" if med is None else "0p05"
+        for k, v in pair_table(list(frames), 96000, med).items():
+            out[f"{k}_{tag}"] = v
+    save("c4_sphere_first12.npz", **out)
+
+
+def golden_c5(frames=(0, 1)):
+    mics = cases.grid_array_64()
+    out = {}
+    keep = ref_sp.generate_signal
+    for f in frames:
+        base = cases.c5_base(f)
+        try:
+            ref_sp.generate_signal = lambda *a, **k: base.copy()
+            sig = ref_main.simulate_signals_with_multipath(cases.c5_source(f), mics, 48000, cases.C_SOUND, 0.25,
+                                                           "noise", 1000, cases.DEFAULT_PLANES, cases.LOW_LOSS, 3, 0.01)
+        finally:
+            ref_sp.generate_signal = keep
+        out[f"f{f}_sim_digest"] = np.array([cases.waveform_digest(s) for s in sig])
+        out.update(stage_outputs(sig, 48000, (0.05,), prefix=f"f{f}_"))
+    save("c5_stream_frames01.npz", **out)
+
+
+def golden_metric(mics=8):
+    frames = cases.metric_frames(1, mics)[0]
+    out = {}
+    for med in (0.05, None):
+        tag = "none" if med is None else "0p05"
+        for k, v in pair_table(list(frames), 44100, med).items():
+            out[f"{k}_{tag}"] = v
+    save("metric_44k1_first8.npz", **out)
+
+
+def golden_selection_edges():
+    """Tiny arrays that force every branch of the fallback chain."""
+    rng = np.random.default_rng(11)
+    rows = []
+    corrs = []
+    t = 0
+    while len(rows) < 160:
+        t += 1
+        n1 = int(rng.integers(24, 200))
+        n2 = n1 if t % 3 else int(rng.integers(24, 200))
+        fs = float(rng.choice([1000.0, 2000.0, 8000.0, 48000.0]))
+        a, b = rng.standard_normal(n1), rng.standard_normal(n2)
+        if t % 5 == 0:
+            a = np.sin(0.31 * np.arange(n1)); b = np.sin(0.31 * np.arange(n2) + 0.4)
+        med = [None, 0.05, 0.01, 0.001, 0.0][t % 5]
+        meth = ["median", "adaptive", "other"][t % 3]
+        mult = [1.0, 3.0, 25.0, 0.2][t % 4]
+        td, corr, lags = ref_utils.get_time_delays_phat(a, b, fs, num_peaks=1, threshold_method=meth,
+                                                        threshold_multiplier=mult, max_expected_delay=med)
+        rows.append([t, n1, n2, fs, -1.0 if med is None else med, ["median", "adaptive", "other"].index(meth), mult,
+                     int(round(td[0] * fs)) + n2 - 1, np.max(corr), np.min(corr), int(np.argmax(corr)),
+                     ref_utils.compute_snr(corr)])
+    save("selection_edges.npz", rows=np.array(rows, dtype=np.float64))
+
+
+def golden_filters():
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(4000)
+    out = {}
+    for fs in (44100, 48000, 96000):
+        out[f"butter_{fs}"] = ref_sp.noise_reduction(x, fs, method="butterworth")
+    out["fir_48000"] = ref_sp.noise_reduction(x, 48000, method="fir")
+    out["wiener"] = ref_sp.noise_reduction(x, 48000, method="wiener")
+    out["fracdelay"] = ref_sp.fractional_delay(x, 0.00123, 48000)
+    out["compress"] = ref_sp.dynamic_range_compression(x)
+    save("filters.npz", **out)
+
+
+def golden_images():
+    mics = np.random.default_rng(2).uniform(-0.5, 0.5, (8, 3))
+    shoebox = [{"plane": [1, 0, 0, -5], "material": "wood"}, {"plane": [1, 0, 0, 4], "material": "wood"},
+               {"plane": [0, 1, 0, -5], "material": "metal"}, {"plane": [0, 1, 0, 3], "material": "metal"},
+               {"plane": [0, 0, 1, -3], "material": "wood"}, {"plane": [0, 0, 1, 1], "material": "air"}]
+    out = {}
+    for order in (1, 2, 3):
+        imgs = ref_utils.generate_image_sources_iterative([1.0, 2.0, 0.5], shoebox, order, 500, cases.LOW_LOSS, mics, 0.01)
+        out[f"shoebox_o{order}"] = np.array([i["source"] for i in imgs]).reshape(-1, 3)
+        out[f"shoebox_o{order}_mat"] = np.array([i["material"] for i in imgs], dtype="U8")
+    for f in (0.01, 0.1, 0.25, 1.0):
+        imgs = ref_utils.generate_image_sources_iterative([1.0, 2.0, 0.5], cases.DEFAULT_PLANES, 3, f,
+                                                          ref_main.material_properties, mics, 0.01)
+        out["default_f%s" % str(f).replace(".", "p")] = np.array([i["source"] for i in imgs]).reshape(-1, 3)
+    save("image_sources.npz", **out)
+
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or ["edges", "filters", "images", "c1", "c2", "metric", "c4", "c5", "c3"]
+    table = {"edges": golden_selection_edges, "filters": golden_filters, "images": golden_images, "c1": golden_c1,
+             "c2": golden_c2, "c3": golden_c3, "c4": golden_c4, "c5": golden_c5, "metric": golden_metric}
+    for key in todo:
+        t0 = time.time()
+        print(f"[{key}]", flush=True)
+        table[key]()
+        print(f"  {time.time() - t0:.1f} s", flush=True)

@@ -1,0 +1,89 @@
+// Host execution of the workgroup FFT stage code of csrc/fft_core.h, lane by lane, against a
+// naive O(N^2) DFT.  Built and run by tests/test_host_fft_core.py (no GPU needed):
+//   hipcc -O2 -I pyaudiolocalization_amd/csrc tests/host/test_fft_core.cpp -o /tmp/test_fft_core
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fft_core.h"
+
+using namespace pal;
+
+static void make_stage_tw(int ln, std::vector<cd>& tw) {
+  tw.assign(1 << ln, mk(0, 0));
+  for (int lp = stage_log2r(ln, 0); lp < ln; lp += stage_log2r(ln, lp)) {
+    const int R = stage_radix(ln, lp), P = 1 << lp, off = stage_tw_offset(ln, lp);
+    for (int r = 1; r < R; ++r)
+      for (int k = 0; k < P; ++k) {
+        const double a = -2.0 * M_PI * double(k * r) / double(P * R);
+        tw[off + (r - 1) * P + k] = mk(std::cos(a), std::sin(a));
+      }
+  }
+}
+
+template <int LOG2N, bool COLS, bool INV, int LOG2P> static void emu_from(std::vector<cd>& data, const std::vector<cd>& tw) {
+  if constexpr (LOG2P < LOG2N) {
+    constexpr int R = stage_radix(LOG2N, LOG2P);
+    constexpr int ITEMS = kPoints / R;
+    std::vector<cd> regs(size_t(ITEMS) * R);
+    for (int w = 0; w < ITEMS; ++w) stage_load<LOG2N, COLS, INV, LOG2P>(data.data(), tw.data(), w, &regs[size_t(w) * R]);
+    for (int w = 0; w < ITEMS; ++w) stage_store<LOG2N, COLS, LOG2P>(data.data(), w, &regs[size_t(w) * R]);
+    emu_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P)>(data, tw);
+  }
+}
+
+template <int LOG2N, bool COLS, bool INV> static double check() {
+  constexpr int N = 1 << LOG2N, T = kPoints / N;
+  std::vector<cd> tw;
+  make_stage_tw(LOG2N, tw);
+  std::vector<cd> data(kPoints);
+  std::vector<cd> plain(kPoints);   // plain[t*N + e]
+  for (int t = 0; t < T; ++t)
+    for (int e = 0; e < N; ++e) {
+      cd v = mk(drand48() - 0.5, drand48() - 0.5);
+      plain[t * N + e] = v;
+      data[lds_addr<LOG2N, COLS>(t, e)] = v;
+    }
+  emu_from<LOG2N, COLS, INV, 0>(data, tw);
+  double worst = 0;
+  const int tstep = T > 8 ? T / 8 : 1;
+  for (int t = 0; t < T; t += tstep)
+    for (int k = 0; k < N; ++k) {
+      long double sx = 0, sy = 0;
+      for (int e = 0; e < N; ++e) {
+        const long double a = (INV ? 2.0L : -2.0L) * M_PIl * (long double)((long long)k * e % N) / N;
+        const long double c = cosl(a), s = sinl(a);
+        sx += plain[t * N + e].x * c - plain[t * N + e].y * s;
+        sy += plain[t * N + e].x * s + plain[t * N + e].y * c;
+      }
+      const cd got = data[lds_addr<LOG2N, COLS>(t, k)];
+      worst = std::fmax(worst, std::fmax(std::fabs(double(got.x - sx)), std::fabs(double(got.y - sy))));
+    }
+  return worst / std::sqrt(double(N));
+}
+
+template <int LOG2N> static int run() {
+  const double e[4] = {check<LOG2N, false, false>(), check<LOG2N, false, true>(), check<LOG2N, true, false>(),
+                       check<LOG2N, true, true>()};
+  int bad = 0;
+  for (int i = 0; i < 4; ++i) bad += !(e[i] < 1e-14);
+  std::printf("N=%5d rows fwd %.2e inv %.2e | cols fwd %.2e inv %.2e | tw entries %d %s\n", 1 << LOG2N, e[0], e[1], e[2],
+              e[3], stage_tw_size(LOG2N), bad ? "FAIL" : "ok");
+  return bad;
+}
+
+int main() {
+  srand48(12345);
+  int bad = 0;
+  bad += run<4>();
+  bad += run<5>();
+  bad += run<6>();
+  bad += run<7>();
+  bad += run<8>();
+  bad += run<9>();
+  bad += run<10>();
+  bad += run<11>();
+  std::printf(bad ? "FAILED\n" : "ALL OK\n");
+  return bad ? 1 : 0;
+}
