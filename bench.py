@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mic-pair GCC-PHAT correlations per second on 44.1 kHz x 1 s frames.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (forward spectra of every mic, all-pairs PHAT whitening +
+exact-length inverse DFT, peak selection with the reference's full fallback chain, SNR/max/min)
+over one batch of synthetic frames that already sits in HBM: 64 mics x 44100 samples per frame,
+2016 pairs per frame, float64 (the reference's precision; selected indices are bit-identical).
+Frames are independent, so N ranks (one process per GPU) each own their frames - weak scaling, no
+data-path collective - and every step ends with ONE all-gather of the 48-byte-per-pair TDOA tables
+(RCCL over xGMI through the engine's own communicator; torch.distributed/gloo only carries the
+barrier, the unique id and the max-over-ranks of the elapsed time).
+
+Rank 0 prints one JSON line.  ``roofline`` prices the dominant kernel, measured live with HIP
+events on the engine's stream inside the timed region; ``cpu_baseline`` times the NumPy oracle
+(same pocketfft calls as the reference) on one host core over a bounded sample of the same frame.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FS = 44100
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def algorithmic_bytes_per_pair(mics: int, length: int, real_bytes: int = 8) -> float:
+    """each pair reads two half spectra and writes one record; each mic frame is
+    read once and its half spectrum written once, amortised over the P pairs."""
+    h = length                      # n = 2L-1 is odd: H = (n+1)/2 = L bins
+    pairs = mics * (mics - 1) // 2
+    return 4 * h * real_bytes + (mics / pairs) * (length * real_bytes + 2 * h * real_bytes) + 64
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1, help="frames per step per GPU")
+    ap.add_argument("--mics", type=int, default=64)
+    ap.add_argument("--length", type=int, default=44100)
+    ap.add_argument("--max-expected-delay", type=float, default=0.05, help="seconds; negative = None")
+    ap.add_argument("--chunk", type=int, default=0, help="transforms per launch group (0 = engine default)")
+    ap.add_argument("--cpu-mics", type=int, default=24, help="mics of frame 0 in the CPU baseline / parity sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    from pyaudiolocalization_amd import Engine, RECORD, make_params, pair_list
+    from pyaudiolocalization_amd.synthetic import metric_frames
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        dist = dist_mod
+
+    eng = Engine(local_rank)
+    if args.chunk > 0:
+        eng.set_chunk(args.chunk)
+    b, m, length = args.frames, args.mics, args.length
+    pairs = m * (m - 1) // 2
+    med = None if args.max_expected_delay < 0 else args.max_expected_delay
+    prm = make_params(FS, 1, "median", 1.0, med)
+
+    frames = metric_frames(b, m, length, first=rank * b)          # this rank's own frames (weak scaling)
+    d_frames = eng.alloc(frames.nbytes)
+    eng.upload(d_frames, frames)
+    tbytes = b * pairs * RECORD.itemsize
+    d_table = eng.alloc(tbytes)
+    d_all = eng.alloc(tbytes * world) if world > 1 else 0
+
+    gather = "none"
+    if world > 1:
+        import torch
+        try:                                                      # engine-native RCCL communicator
+            ident = [Engine.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            eng.comm_init(world, rank, ident[0])
+            gather = "rccl-allgather"
+        except Exception as exc:                                  # reported, never silent
+            print(f"[rank {rank}] RCCL init failed ({exc}); gathering through gloo host tensors", file=sys.stderr)
+            gather = "gloo-host"
+        flags = [None] * world
+        dist.all_gather_object(flags, gather)
+        if any(f != "rccl-allgather" for f in flags):
+            gather = "gloo-host"
+
+    host_table = np.zeros((b, pairs), dtype=RECORD)
+
+    def step() -> None:
+        eng.gcc_phat_all_pairs_dev(d_frames, b, m, length, prm, d_table)
+        if gather == "rccl-allgather":
+            eng.all_gather_dev(d_table, d_all, tbytes)
+        elif gather == "gloo-host":
+            from pyaudiolocalization_amd.distributed import gather_tables_torch
+            eng.synchronize()
+            eng.download(host_table, d_table)
+            gather_tables_torch(host_table, b * world, rank, world)
+
+    def barrier() -> None:
+        eng.synchronize()
+        if dist is not None:
+            dist.barrier()
+        eng.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.profile_end()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    eng.download(host_table, d_table)
+    total_pairs = args.steps * b * pairs * world
+    value = total_pairs / elapsed
+
+    # ---- dominant kernel, HIP events on the engine's stream --------------------------------------
+    entries = eng.profile_entries()
+    kernels = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in entries.items() if v[1] > 0}
+    dom = max(entries.items(), key=lambda kv: kv[1][0]) if entries else ("none", (0.0, 0))
+    dom_name, (dom_ms, dom_launches) = dom
+    b_alg = algorithmic_bytes_per_pair(m, length)
+    local_pairs = args.steps * b * pairs
+    roofline = None
+    if dom_launches:
+        avg_s = dom_ms * 1e-3 / dom_launches
+        achieved = b_alg * (local_pairs / dom_launches) / avg_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom_name)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": dom_name,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": dom_launches,
+                    "algorithmic_bytes_per_pair": round(b_alg, 1), "pairs_per_launch": round(local_pairs / dom_launches, 2)}
+
+    # ---- CPU baseline + parity sample (rank 0, N = 1 only) ---------------------------------------------
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pal_oracle as O                       # checker + baseline only, never the product path
+        cm = min(args.cpu_mics, m)
+        t1 = time.perf_counter()
+        want = O.all_pairs(frames[0, :cm], FS, max_expected_delay=med)
+        cpu_s = time.perf_counter() - t1
+        cpairs = cm * (cm - 1) // 2
+        cpu = {"value": round(cpairs / cpu_s, 2), "unit": "pair-correlations/s", "cores": 1, "kind": "port",
+               "sample": f"all {cpairs} pairs of the first {cm} mics of frame 0 ({cpu_s:.1f} s, NumPy/pocketfft oracle, "
+                         "3 exact-length FFTs per pair like utils.py:114-118)"}
+        full = pair_list(m)
+        pick = np.flatnonzero((full[:, 0] < cm) & (full[:, 1] < cm))
+        got = host_table[0][pick]
+        parity = {"pairs_checked": int(cpairs), "k_sel_equal": int(np.count_nonzero(got["k_sel"] == want["k_sel"])),
+                  "branch_equal": int(np.count_nonzero(got["branch"] == want["branch"])),
+                  "max_rel_err_cmax": float(np.max(np.abs(got["cmax"] - want["cmax"]) / np.abs(want["cmax"])))}
+
+    if rank == 0:
+        info = eng.plan_info(length)
+        line = {
+            "metric": "mic-pair GCC-PHAT correlations/s @44.1kHz·1s",
+            "value": round(value, 1), "unit": "pair-correlations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"metric run: {b} frame(s)/step/GPU x {m} mics x {length} samples @ {FS} Hz, "
+                                   f"{pairs} pairs/frame, max_expected_delay={med}, exact DFT length n={info['n']} "
+                                   f"via chirp convolution {info['m1']}x{info['m2']}",
+                       "frames_per_step_per_gpu": b, "mics": m, "samples": length, "pairs_per_frame": pairs,
+                       "gather": gather, "parallelism": f"frames sharded over {world} GPU(s)"},
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels_ms": kernels,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

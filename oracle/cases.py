@@ -98,16 +98,40 @@ def c5_base(frame: int) -> np.ndarray:
 
 
 def metric_frames(batch: int, mics: int = 64, n: int = 44100, first: int = 0) -> np.ndarray:
-    """Frames of the metric run: independent noise per mic plus one common component with an integer
-    per-mic delay.  Frame ``b`` depends only on ``b`` so shards of a batch can be built per rank."""
-    delays = np.random.default_rng(8).integers(-60, 60, size=64)[:mics]
-    out = np.empty((batch, mics, n))
-    for b in range(batch):
-        g = np.random.default_rng([7, first + b])
-        common = g.standard_normal(n + 200)
-        out[b] = g.standard_normal((mics, n))
-        for m in range(mics):
-            out[b, m] += common[100 + delays[m]: 100 + delays[m] + n]
+    """Frames of the metric run (defined next to bench.py's generator so both use one recipe)."""
+    from pyaudiolocalization_amd.synthetic import metric_frames as make
+    return make(batch, mics, n, first)
+
+
+SHOEBOX = [{"plane": [1, 0, 0, -5], "material": "wood"}, {"plane": [1, 0, 0, 4], "material": "wood"},
+           {"plane": [0, 1, 0, -5], "material": "metal"}, {"plane": [0, 1, 0, 3], "material": "metal"},
+           {"plane": [0, 0, 1, -3], "material": "wood"}, {"plane": [0, 0, 1, 1], "material": "air"}]
+
+
+def selection_edge_cases(count: int = 160):
+    """Tiny signal pairs and parameter mixes that force every branch of the peak-selection fallback chain
+    (SURVEY 8c item 3): unequal lengths, sines, 'adaptive' / unknown methods, tight and zero windows."""
+    rng = np.random.default_rng(11)
+    out = []
+    t = 0
+    while len(out) < count:
+        t += 1
+        n1 = int(rng.integers(24, 200))
+        n2 = n1 if t % 3 else int(rng.integers(24, 200))
+        fs = float(rng.choice([1000.0, 2000.0, 8000.0, 48000.0]))
+        a, b = rng.standard_normal(n1), rng.standard_normal(n2)
+        if t % 5 == 0:
+            a = np.sin(0.31 * np.arange(n1))
+            b = np.sin(0.31 * np.arange(n2) + 0.4)
+        out.append({"t": t, "a": a, "b": b, "fs": fs, "med": [None, 0.05, 0.01, 0.001, 0.0][t % 5],
+                    "method": ["median", "adaptive", "other"][t % 3], "mult": [1.0, 3.0, 25.0, 0.2][t % 4]})
+    # degenerate inputs: no interior peak at all (delta / all-zero / one-sided sequences), even n
+    ramp = np.arange(1.0, 41.0)
+    extra = [(np.ones(40), np.ones(40), None), (np.zeros(50), np.zeros(50), 0.01), (ramp, ramp[::-1].copy(), None),
+             (np.ones(33), np.ones(32), 0.005), (rng.standard_normal(64), np.zeros(64), None),
+             (rng.standard_normal(65), rng.standard_normal(64), 0.002)]
+    for k, (a, b, med) in enumerate(extra):
+        out.append({"t": 10000 + k, "a": a, "b": b, "fs": 2000.0, "med": med, "method": "median", "mult": 1.0})
     return out
 
 

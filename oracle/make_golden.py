@@ -189,27 +189,15 @@ def golden_metric(mics=8):
 
 
 def golden_selection_edges():
-    """Tiny arrays that force every branch of the fallback chain."""
-    rng = np.random.default_rng(11)
+    """Reference outputs for oracle/cases.selection_edge_cases (every branch of the fallback chain)."""
     rows = []
-    corrs = []
-    t = 0
-    while len(rows) < 160:
-        t += 1
-        n1 = int(rng.integers(24, 200))
-        n2 = n1 if t % 3 else int(rng.integers(24, 200))
-        fs = float(rng.choice([1000.0, 2000.0, 8000.0, 48000.0]))
-        a, b = rng.standard_normal(n1), rng.standard_normal(n2)
-        if t % 5 == 0:
-            a = np.sin(0.31 * np.arange(n1)); b = np.sin(0.31 * np.arange(n2) + 0.4)
-        med = [None, 0.05, 0.01, 0.001, 0.0][t % 5]
-        meth = ["median", "adaptive", "other"][t % 3]
-        mult = [1.0, 3.0, 25.0, 0.2][t % 4]
-        td, corr, lags = ref_utils.get_time_delays_phat(a, b, fs, num_peaks=1, threshold_method=meth,
-                                                        threshold_multiplier=mult, max_expected_delay=med)
-        rows.append([t, n1, n2, fs, -1.0 if med is None else med, ["median", "adaptive", "other"].index(meth), mult,
-                     int(round(td[0] * fs)) + n2 - 1, np.max(corr), np.min(corr), int(np.argmax(corr)),
-                     ref_utils.compute_snr(corr)])
+    for case in cases.selection_edge_cases():
+        td, corr, lags = ref_utils.get_time_delays_phat(case["a"], case["b"], case["fs"], num_peaks=1,
+                                                        threshold_method=case["method"],
+                                                        threshold_multiplier=case["mult"], max_expected_delay=case["med"])
+        n2 = len(case["b"])
+        rows.append([case["t"], int(round(td[0] * case["fs"])) + n2 - 1, np.max(corr), np.min(corr), int(np.argmax(corr)),
+                     ref_utils.compute_snr(corr), ref_utils.compute_peak_to_peak_ratio(corr)])
     save("selection_edges.npz", rows=np.array(rows, dtype=np.float64))
 
 
@@ -228,9 +216,7 @@ def golden_filters():
 
 def golden_images():
     mics = np.random.default_rng(2).uniform(-0.5, 0.5, (8, 3))
-    shoebox = [{"plane": [1, 0, 0, -5], "material": "wood"}, {"plane": [1, 0, 0, 4], "material": "wood"},
-               {"plane": [0, 1, 0, -5], "material": "metal"}, {"plane": [0, 1, 0, 3], "material": "metal"},
-               {"plane": [0, 0, 1, -3], "material": "wood"}, {"plane": [0, 0, 1, 1], "material": "air"}]
+    shoebox = cases.SHOEBOX
     out = {}
     for order in (1, 2, 3):
         imgs = ref_utils.generate_image_sources_iterative([1.0, 2.0, 0.5], shoebox, order, 500, cases.LOW_LOSS, mics, 0.01)

@@ -284,7 +284,11 @@ def fractional_delay(signal: np.ndarray, delay: float, fs: float) -> np.ndarray:
     n = x.shape[0]
     spec = np.fft.fft(x, n=2 * n)
     f = np.fft.fftfreq(2 * n, d=1.0 / fs)
-    y = np.fft.ifft(spec * np.exp(-1j * 2 * np.pi * f * delay)).real[:n]
+    # both factors are named arrays as in signal_processing.py:71-72: with a temporary on the right NumPy
+    # multiplies in place in the other operand order, and its FMA complex product is not bitwise commutative
+    phase = np.exp(-1j * 2 * np.pi * f * delay)
+    product = spec * phase
+    y = np.fft.ifft(product).real[:n]
     return y * fade_window(n)
 
 

@@ -1,0 +1,286 @@
+// bluestein.hip - exact-length DFTs for GCC-PHAT on gfx950 (fp64, no MFMA: the work is
+// butterflies and streaming, not a dense contraction).
+//
+// Replaces numpy.fft.fft(sig, n) / numpy.fft.ifft(R) of utils.py:114-118 at the exact length
+// n = n1 + n2 - 1 (zero-padding to a smooth length changes the selected peaks).
+//
+//   DFT_n(x)[k] = conj(w_k) * sum_j (x_j conj(w_j)) w_{k-j},   w_j = exp(i pi j^2 / n)
+//
+// i.e. one circular convolution of power-of-two length M = M1 x M2 with a fixed chirp.  It runs as
+// three launches over a resident HBM workspace W[g][M] (g = transform within a launch group):
+//
+//   cols_fwd : build the input on the fly (loader functor), M1-point column FFTs in LDS,
+//              four-step twiddle, write W                         (read: source, write: 16 B/pt)
+//   rows_conv: M2-point row FFT, multiply by the chirp spectrum (L2/Infinity-Cache resident,
+//              shared by every transform), M2-point inverse row FFT, in place   (16 B r + 16 B w)
+//   cols_inv : conj twiddle, M1-point inverse column FFTs, hand y[j] to a storer functor
+//
+// The inverse PHAT transform packs two mic pairs into one complex transform (real part = pair p,
+// imaginary part = pair q) and whitens R = S_a conj(S_b) / (|.| + 1e-10) inside the loader, so the
+// whitened cross spectrum never exists in memory.
+#include <cmath>
+
+#include "conv_kernels.h"
+
+namespace pal {
+
+// ------------------------------------------------------------------ table generators
+__global__ void k_make_chirp(cd* w, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  unsigned long long r = (unsigned long long)j * (unsigned long long)j % (2ull * (unsigned long long)n);
+  double sgn = 1.0;
+  if (r >= (unsigned long long)n) { r -= n; sgn = -1.0; }
+  double s, c;
+  sincospi(double(r) / double(n), &s, &c);
+  w[j] = mk(sgn * c, sgn * s);
+}
+
+// out[q] = exp(-2 pi i q / denom)
+__global__ void k_make_roots(cd* out, int count, double denom) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= count) return;
+  double s, c;
+  sincospi(-2.0 * double(q) / denom, &s, &c);
+  out[q] = mk(c, s);
+}
+
+__global__ void k_make_stage_tw(cd* out, int ln) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int lp = stage_log2r(ln, 0); lp < ln; lp += stage_log2r(ln, lp)) {
+    const int R = stage_radix(ln, lp), P = 1 << lp, off = stage_tw_offset(ln, lp);
+    if (idx >= off && idx < off + (R - 1) * P) {
+      const int r = (idx - off) / P + 1, k = (idx - off) % P;
+      double s, c;
+      sincospi(-2.0 * double(k * r) / double(P * R), &s, &c);
+      out[idx] = mk(c, s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ loader / storer functors
+// chirp kernel of the convolution: c[m mod M] = w_|m| (or its conjugate) for -neg < m < pos
+struct ChirpLoader {
+  static constexpr const char* kName = "ChirpLoader";
+  const cd* w;
+  int neg, pos;
+  unsigned M;
+  bool conj_kernel;
+  __device__ cd operator()(int, unsigned j) const {
+    unsigned a;
+    if (j < (unsigned)pos) a = j;
+    else if (M - j < (unsigned)neg) a = M - j;
+    else return mk(0, 0);
+    cd v = w[a];
+    return conj_kernel ? cconj(v) : v;
+  }
+};
+
+// forward transform input: x_j conj(w_j)
+struct FrameLoader {
+  static constexpr const char* kName = "FrameLoader";
+  const double* x;
+  size_t stride;
+  int len;
+  const cd* w;
+  __device__ cd operator()(int g, unsigned j) const {
+    if (j >= (unsigned)len) return mk(0, 0);
+    const double v = x[size_t(g) * stride + j];
+    const cd c = w[j];
+    return mk(v * c.x, -v * c.y);
+  }
+};
+
+// forward transform output: X_k = conj(w_k) y_k, k < H
+struct SpectrumStorer {
+  static constexpr const char* kName = "SpectrumStorer";
+  cd* S;
+  int H;
+  const cd* w;
+  __device__ void operator()(int g, unsigned j, cd y) const {
+    if (j < (unsigned)H) S[size_t(g) * H + j] = cmulc(y, w[j]);
+  }
+};
+
+// R = S_a conj(S_b);  R /= |R| + 1e-10        (utils.py:116-117)
+__device__ __forceinline__ cd whiten(cd a, cd b) {
+  const cd r = cmulc(a, b);
+  const double inv = 1.0 / (sqrt(r.x * r.x + r.y * r.y) + 1e-10);
+  return mk(r.x * inv, r.y * inv);
+}
+
+// inverse transform input: (R^p_k + i R^q_k) w_k over the full Hermitian-extended grid k < n
+struct PairLoader {
+  static constexpr const char* kName = "PairLoader";
+  const cd* S;       // spectra[row][H]
+  const int4* quad;  // rows (a, b) of pair p and (c, d) of pair q; c < 0: no second pair
+  int n, H;
+  const cd* w;
+  __device__ cd operator()(int g, unsigned j) const {
+    if (j >= (unsigned)n) return mk(0, 0);
+    const bool mirror = j >= (unsigned)H;
+    const unsigned jj = mirror ? n - j : j;
+    const int4 q = quad[g];
+    cd r1 = whiten(S[size_t(q.x) * H + jj], S[size_t(q.y) * H + jj]);
+    cd r2 = mk(0, 0);
+    if (q.z >= 0) r2 = whiten(S[size_t(q.z) * H + jj], S[size_t(q.w) * H + jj]);
+    if (mirror) { r1.y = -r1.y; r2.y = -r2.y; }
+    return cmul(mk(r1.x - r2.y, r1.y + r2.x), w[j]);
+  }
+};
+
+// inverse transform output: z_m = w_m y_m; real part -> row 2g, imaginary part -> row 2g+1
+struct CorrStorer {
+  static constexpr const char* kName = "CorrStorer";
+  double* corr;
+  size_t stride;
+  int n;
+  const cd* w;
+  __device__ void operator()(int g, unsigned j, cd y) const {
+    if (j >= (unsigned)n) return;
+    const cd z = cmul(y, w[j]);
+    corr[size_t(2 * g) * stride + j] = z.x;
+    corr[size_t(2 * g + 1) * stride + j] = z.y;
+  }
+};
+
+// ------------------------------------------------------------------ plans
+const cd* Engine::stage_table(int ln) {
+  if (!stage_tw[ln]) {
+    cd* p = nullptr;
+    if (hipMalloc(&p, sizeof(cd) << ln) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(p, 0, sizeof(cd) << ln, stream);
+    k_make_stage_tw<<<dim3(((1 << ln) + 255) / 256), dim3(256), 0, stream>>>(p, ln);
+    stage_tw[ln] = p;
+  }
+  return stage_tw[ln];
+}
+
+static void split_log2(int lm, int& l1, int& l2) {
+  l2 = lm <= 19 ? (lm - 6 < 10 ? lm - 6 : 10) : 11;
+  l1 = lm - l2;
+}
+
+int Engine::alloc_conv(Conv& c, int lm) {
+  if (lm < 12) lm = 12;
+  if (lm > 22) return fail(PAL_ERR_UNSUPPORTED, "convolution length 2^%d exceeds 2^22", lm);
+  c.lm = lm;
+  split_log2(lm, c.l1, c.l2);
+  if (!stage_table(c.l1) || !stage_table(c.l2)) return fail(PAL_ERR_NOMEM, "twiddle tables");
+  const size_t M = c.M();
+  PAL_HIP(hipMalloc(&c.chat, M * sizeof(cd)));
+  PAL_HIP(hipMalloc(&c.twA, sizeof(cd) << c.l1));
+  PAL_HIP(hipMalloc(&c.twB, sizeof(cd) << c.l2));
+  k_make_roots<<<dim3(((1 << c.l1) + 255) / 256), dim3(256), 0, stream>>>(c.twA, 1 << c.l1, double(1 << c.l1));
+  k_make_roots<<<dim3(((1 << c.l2) + 255) / 256), dim3(256), 0, stream>>>(c.twB, 1 << c.l2, double(M));
+  return check(hipGetLastError(), "k_make_roots");
+}
+
+void Engine::free_conv(Conv& c) {
+  if (c.chat) (void)hipFree(c.chat);
+  if (c.twA) (void)hipFree(c.twA);
+  if (c.twB) (void)hipFree(c.twB);
+  c = Conv();
+}
+
+int Engine::build_conv(Conv& c, const cd* w, int n, int neg_count, int pos_count, bool conj_kernel,
+                       double extra_scale) {
+  Engine* e = this;
+  PAL_TRY(alloc_conv(c, ceil_log2(size_t(neg_count) + size_t(pos_count) - 1)));
+  // chirp spectrum: column FFTs + twiddle, then forward row FFTs, scaled, in [k1][k2] order
+  ChirpLoader ld{w, neg_count, pos_count, unsigned(c.M()), conj_kernel};
+  PAL_TRY(launch_cols_fwd(e, c, 1, ld, c.chat));
+  PAL_TRY(launch_rows(e, c, 1, c.chat, false, extra_scale / double(c.M())));
+  return PAL_OK;
+}
+
+int Engine::get_plan(int n, int lin, int nout, Plan** out) {
+  auto key = std::make_tuple(n, lin, nout);
+  auto it = plans.find(key);
+  if (it != plans.end()) {
+    *out = &it->second;
+    return PAL_OK;
+  }
+  if (n < 1 || lin < 1 || lin > n || nout < 1 || nout > n)
+    return fail(PAL_ERR_INVALID, "bad transform geometry n=%d lin=%d nout=%d", n, lin, nout);
+  Plan pl;
+  pl.n = n;
+  pl.H = n / 2 + 1;
+  pl.lin = lin;
+  pl.nout = nout;
+  PAL_HIP(hipMalloc(&pl.w, size_t(n) * sizeof(cd)));
+  k_make_chirp<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(pl.w, n);
+  PAL_HIP(hipGetLastError());
+  // forward: j < lin inputs, k < H outputs, kernel w_{k-j}
+  PAL_TRY(build_conv(pl.fwd, pl.w, n, lin, pl.H, false, 1.0));
+  // inverse: k < n inputs, m < nout outputs, kernel conj(w_{m-k}); 1/n of numpy.fft.ifft folded in
+  PAL_TRY(build_conv(pl.inv, pl.w, n, n, nout, true, 1.0 / double(n)));
+  PAL_HIP(hipStreamSynchronize(stream));
+  auto ins = plans.emplace(key, pl);
+  *out = &ins.first->second;
+  return PAL_OK;
+}
+
+// ------------------------------------------------------------------ pipelines
+int Engine::forward_spectra(Plan& pl, const double* frames, size_t frame_stride, int rows, int len, cd* spectra) {
+  Engine* e = this;
+  if (len > pl.lin) return fail(PAL_ERR_INVALID, "frame length %d exceeds plan input length %d", len, pl.lin);
+  const Conv& c = pl.fwd;
+  void* wsp = nullptr;
+  PAL_TRY(scratch(0, size_t(chunk) * c.M() * sizeof(cd), &wsp));
+  cd* W = static_cast<cd*>(wsp);
+  for (int r0 = 0; r0 < rows; r0 += chunk) {
+    const int G = rows - r0 < chunk ? rows - r0 : chunk;
+    FrameLoader ld{frames + size_t(r0) * frame_stride, frame_stride, len, pl.w};
+    SpectrumStorer st{spectra + size_t(r0) * pl.H, pl.H, pl.w};
+    PAL_TRY(launch_cols_fwd(e, c, G, ld, W));
+    PAL_TRY(launch_rows(e, c, G, W, true, 1.0));
+    PAL_TRY(launch_cols_inv(e, c, G, W, st));
+  }
+  return PAL_OK;
+}
+
+int Engine::pair_correlations(Plan& pl, const cd* spectra, const int4* quads, int64_t npairs, int n2,
+                              const pal_phat_params& prm, pal_pair_record* table, int32_t* ksel_multi,
+                              double* corr_out) {
+  Engine* e = this;
+  const Conv& c = pl.inv;
+  const int n = pl.n;
+  void* wsp = nullptr;
+  PAL_TRY(scratch(0, size_t(chunk) * c.M() * sizeof(cd), &wsp));
+  cd* W = static_cast<cd*>(wsp);
+  const size_t stride = corr_out ? size_t(n) : (size_t(n) + 1) & ~size_t(1);
+  double* cbuf = nullptr;
+  if (!corr_out) {
+    void* p = nullptr;
+    PAL_TRY(scratch(1, size_t(2 * chunk) * stride * sizeof(double), &p));
+    cbuf = static_cast<double*>(p);
+  }
+  const int64_t ntr = (npairs + 1) / 2;
+  for (int64_t t0 = 0; t0 < ntr; t0 += chunk) {
+    const int G = int(ntr - t0 < chunk ? ntr - t0 : chunk);
+    const int64_t p0 = 2 * t0;
+    const int rows = int(npairs - p0 < 2 * G ? npairs - p0 : 2 * G);
+    double* crow = corr_out ? corr_out + size_t(p0) * stride : cbuf;
+    if (corr_out && rows < 2 * G) {
+      // odd tail: the imaginary half of the last transform has no destination row in the caller's
+      // buffer, run that transform through scratch instead
+      void* p = nullptr;
+      PAL_TRY(scratch(1, size_t(2 * chunk) * stride * sizeof(double), &p));
+      crow = static_cast<double*>(p);
+    }
+    PairLoader ld{spectra, quads + t0, n, pl.H, pl.w};
+    CorrStorer st{crow, stride, n, pl.w};
+    PAL_TRY(launch_cols_fwd(e, c, G, ld, W));
+    PAL_TRY(launch_rows(e, c, G, W, true, 1.0));
+    PAL_TRY(launch_cols_inv(e, c, G, W, st));
+    if (corr_out && rows < 2 * G) {
+      PAL_HIP(hipMemcpyAsync(corr_out + size_t(p0) * stride, crow, size_t(rows) * stride * sizeof(double),
+                             hipMemcpyDeviceToDevice, stream));
+    }
+    if (table) PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr));
+  }
+  return PAL_OK;
+}
+
+}  // namespace pal

@@ -1,0 +1,233 @@
+"""Drop-in for the reference's main.py: same ``config`` dict, ``simulate_signals_with_multipath`` and
+``localize_sound_source`` signatures and result dict (main.py:26-64, :66-79, :126, :326-333).
+
+What changed underneath: the per-(mic, path) fractional-delay loop (main.py:104-118) is one batched
+HIP launch group, and the i<j pair loop around get_time_delays_phat (main.py:202-228) is one call
+that returns the whole TDOA table.  The 3-unknown position solve stays on the host with the same
+SciPy / scikit-learn calls as the reference (out of GPU scope).
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from .engine import default_engine, pair_list
+from .materials import material_properties  # module-level table, used regardless of config
+from .signal_processing import generate_signal, noise_reduction_rows
+from .utils import (bootstrap_significance, calculate_attenuation, compute_weights, distance, dynamic_bounds_extended,
+                    equations, generate_image_sources_iterative, heuristic_initialization_adaptive, read_audio_files,
+                    speed_of_sound, synchronize_signals_improved)
+
+log = logging.getLogger(__name__)
+
+config = {
+    "fs": 44100,
+    "duration": 1.0,
+    "celsius": 20,
+    "humidity": 50,
+    "mic_positions": [[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]],
+    "source_position": [0.5, 0.5, 0.5],
+    "signal_type": "sine",
+    "freq": 1000,
+    "reflective_planes": [
+        {"plane": [1, 0, 0, -5], "material": "wood"},
+        {"plane": [0, 1, 0, -5], "material": "metal"},
+        {"plane": [0, 0, 1, -5], "material": "wood"},
+    ],
+    "calibration": {"signal_type": "chirp", "freq_start": 500, "freq_end": 5000, "attenuation_factor": 1.0,
+                    "noise_level": 0.01},
+    "localization": {"max_reflections": 3, "filter_method": "butterworth", "absorption_threshold": 0.01,
+                     "analyze_correlation": True, "visualize_correlation": True, "clustering_method": "kmeans",
+                     "clustering_eps": 0.001, "clustering_min_samples": 2, "max_expected_delay": 0.05},
+}
+
+
+def multipath_geometry(source_pos, mic_positions, c, freq, reflective_planes, material_properties, max_reflections,
+                       absorption_threshold):
+    """Per-mic path table: delays[M][1+I] seconds and gains[M][1+I], direct path first with material
+    'air' (main.py:106-108) then the image sources in discovery order (main.py:111-116), and the
+    longest delay over all mics and paths (main.py:93-101)."""
+    images = generate_image_sources_iterative(source=source_pos, planes=reflective_planes, max_order=max_reflections,
+                                              frequency=freq, material_properties=material_properties,
+                                              mic_positions=mic_positions, absorption_threshold=absorption_threshold)
+    mics = np.asarray(mic_positions, dtype=np.float64)
+    delays = np.zeros((mics.shape[0], 1 + len(images)))
+    gains = np.zeros_like(delays)
+    longest = 0
+    for m, mic in enumerate(mics):
+        dists = [distance(source_pos, mic)] + [distance(img["source"], mic) for img in images]
+        mats = ["air"] + [img["material"] for img in images]
+        for p, (d, mat) in enumerate(zip(dists, mats)):
+            delays[m, p] = d / c
+            gains[m, p] = calculate_attenuation(d, mat, freq, material_properties)
+        longest = max(longest, max(dists) / c)
+    return delays, gains, longest
+
+
+def simulate_signals_with_multipath(source_pos, mic_positions, fs, c, duration=1.0, signal_type="sine", freq=1000,
+                                    reflective_planes=None, material_properties=None, max_reflections=2,
+                                    absorption_threshold=0.01, trim_to_duration=True):
+    """Image-source multipath simulation (main.py:66-124): list of M signals of int(duration*fs) samples,
+    each normalised and compressed.  Geometry on the host, synthesis on the HIP engine."""
+    base = generate_signal(signal_type, fs, duration, freq)
+    delays, gains, longest = multipath_geometry(source_pos, mic_positions, c, freq, reflective_planes,
+                                                material_properties, max_reflections, absorption_threshold)
+    total = int((duration + longest) * fs)                                    # main.py:102
+    trim = int(duration * fs) if trim_to_duration else 0                      # main.py:119-120
+    out = default_engine().simulate_multipath(base[None], fs, total, delays[None], gains[None], trim)
+    return [row.copy() for row in out[0]]
+
+
+def tdoa_table(frames: np.ndarray, fs: float, max_expected_delay: Optional[float] = None, threshold_method="median",
+               threshold_multiplier=1.0, want_corr=False):
+    """The pair loop of main.py:202-228 as one engine call: frames[M][L] or [B][M][L] ->
+    structured table[(B,) P] in row-major i<j order (fields of _ffi.RECORD) [+ corr]."""
+    return default_engine().gcc_phat_all_pairs(frames, fs, 1, threshold_method, threshold_multiplier,
+                                               max_expected_delay, want_corr)
+
+
+def _warn_branches(table) -> None:
+    for bit, text in ((_ffi.BR_ALT_THRESHOLD, "primary threshold found no peaks"),
+                      (_ffi.BR_ARGMAX_NO_PEAKS, "no peaks at all, correlation maximum used"),
+                      (_ffi.BR_WINDOW_RETRY, "no peak inside the expected delay range"),
+                      (_ffi.BR_ARGMAX_WINDOW, "no valid peak after alternative filtering, correlation maximum used")):
+        hit = int(np.count_nonzero(table["branch"] & bit))
+        if hit:
+            log.warning("%s for %d microphone pair(s)", text, hit)
+
+
+def localize_sound_source(config, calibration_data=None, audio_files=None, use_simulation=True, show_plots=True):
+    fs = config["fs"]
+    duration = config["duration"]
+    mic_positions = np.array(config["mic_positions"])
+    source_position = config["source_position"]
+    signal_type = config["signal_type"]
+    freq = config["freq"]
+    reflective_planes = config.get("reflective_planes", [])
+    loc = config.get("localization", {})
+    filter_method = loc.get("filter_method", "butterworth")
+    max_reflections = loc.get("max_reflections", 2)
+    absorption_threshold = loc.get("absorption_threshold", 0.01)
+    analyze_correlation = loc.get("analyze_correlation", False)
+    visualize_correlation = loc.get("visualize_correlation", False)
+    clustering_method = loc.get("clustering_method", "kmeans")
+    clustering_eps = loc.get("clustering_eps", 0.001)
+    clustering_min_samples = loc.get("clustering_min_samples", 2)
+    max_expected_delay = loc.get("max_expected_delay", None)
+
+    calib_delays = None
+    if calibration_data is not None:                                           # main.py:147-157
+        if len(calibration_data) != len(mic_positions):
+            log.warning("calibration entries do not match the microphone count, ignoring calibration")
+        else:
+            try:
+                calib_delays = np.array([d.get("delay", 0.0) for d in calibration_data], dtype=float)
+                log.info("calibration correction enabled")
+            except Exception as exc:
+                log.warning("cannot use calibration data (%s), ignoring calibration", exc)
+                calib_delays = None
+
+    c = speed_of_sound(config["celsius"], config["humidity"])
+    log.info("speed of sound: %.2f m/s", c)
+
+    if use_simulation:
+        if source_position is None:
+            raise ValueError("source_position is required when use_simulation=True")
+        signals = simulate_signals_with_multipath(source_pos=source_position, mic_positions=mic_positions, fs=fs, c=c,
+                                                  duration=duration, signal_type=signal_type, freq=freq,
+                                                  reflective_planes=reflective_planes,
+                                                  material_properties=material_properties,
+                                                  max_reflections=max_reflections,
+                                                  absorption_threshold=absorption_threshold, trim_to_duration=True)
+    else:
+        if audio_files is None:
+            raise ValueError("audio_files are required when use_simulation=False")
+        if len(audio_files) != len(mic_positions):
+            raise ValueError("the number of audio files must equal the number of microphones")
+        signals = read_audio_files(audio_files, fs)
+
+    signals = synchronize_signals_improved(signals, fs)                       # main.py:188
+    filtered = noise_reduction_rows(np.asarray(signals), fs, method=filter_method)   # main.py:191, one launch
+
+    # ---- main.py:195-228 as one table -------------------------------------------------------
+    m = len(mic_positions)
+    pairs = pair_list(m)
+    res = tdoa_table(filtered, fs, max_expected_delay, want_corr=visualize_correlation)
+    table, corr_rows = res if visualize_correlation else (res, None)
+    if len(table) == 0:
+        raise RuntimeError("no microphone pairs with an estimated time delay")   # main.py:230-231
+    _warn_branches(table)
+    n2 = filtered.shape[1]
+    td_diffs, mic_pairs = [], []
+    corr_matrix = np.zeros((m, m))
+    correlation_metrics: Dict[Any, Any] = {}
+    for row, (i, j) in zip(table, pairs):
+        i, j = int(i), int(j)
+        td = (np.int64(row["k_sel"]) - (n2 - 1)) / fs                          # time_lags[k] (utils.py:141-142)
+        if calib_delays is not None:
+            td = td - (calib_delays[j] - calib_delays[i])                     # main.py:209-212
+        td_diffs.append(td)
+        mic_pairs.append((i, j))
+        if analyze_correlation:                                                # main.py:219-222, utils.py:261-271
+            ratio = np.inf if row["cmin"] == 0 else row["cmax"] / abs(row["cmin"])
+            limit = bootstrap_significance(filtered[i], filtered[j], fs, alpha=0.05)
+            snr = float(row["snr"])
+            correlation_metrics[(i, j)] = {"peak_to_peak_ratio": ratio, "snr": snr,
+                                           "significant": bool(row["cmax"] > limit) and snr > 2.0}
+        corr_matrix[i, j] = corr_matrix[j, i] = row["cmax"]                   # main.py:223-225
+
+    # ---- host tail: main.py:233-298 ---------------------------------------------------------------
+    from scipy.optimize import differential_evolution, least_squares
+    guesses = heuristic_initialization_adaptive(mic_positions, mic_pairs, td_diffs, c, clustering_method=clustering_method,
+                                                eps=clustering_eps, min_samples=clustering_min_samples)
+    bounds = dynamic_bounds_extended(mic_positions, td_diffs, c, buffer=5.0)
+    lower = [b[0] for b in bounds]
+    upper = [b[1] for b in bounds]
+    guesses = [np.array([np.clip(g[k], lower[k], upper[k]) for k in range(len(g))]) for g in guesses]
+    weights = compute_weights(correlation_metrics, mic_pairs) if analyze_correlation and correlation_metrics \
+        else np.ones(len(mic_pairs))
+    best = None
+    for guess in guesses:
+        fit = least_squares(equations, guess, args=(mic_positions, mic_pairs, td_diffs, c, weights), bounds=(lower, upper),
+                            method="trf", ftol=1e-6, xtol=1e-6, gtol=1e-6)
+        if fit.success and (best is None or fit.cost < best.cost):
+            best = fit
+    if best is not None:
+        position = np.array(best.x)
+    else:
+        log.warning("least squares failed for every start, trying differential evolution")
+        de = differential_evolution(lambda v: np.sum(np.square(equations(v, mic_positions, mic_pairs, td_diffs, c, weights))),
+                                    bounds=list(zip(lower, upper)), strategy="best1bin", maxiter=1000, popsize=15, tol=1e-6,
+                                    mutation=(0.5, 1), recombination=0.7, polish=True, init="latinhypercube")
+        position = np.array(de.x) if de.success else np.array(guesses[0])
+    log.info("estimated source: (%.3f, %.3f, %.3f) m", *position)
+
+    # ---- plots: main.py:300-319 (files are written when show_plots is False) ------------
+    if use_simulation:
+        import matplotlib.pyplot as plt
+        fig = plt.figure()
+        ax = fig.add_subplot(111, projection="3d")
+        ax.scatter(mic_positions[:, 0], mic_positions[:, 1], mic_positions[:, 2], c="r", marker="o", label="microphones")
+        ax.scatter(*source_position, c="g", marker="*", s=100, label="actual source")
+        ax.scatter(*position, c="b", marker="x", s=100, label="estimated source")
+        ax.set_xlabel("X (m)"); ax.set_ylabel("Y (m)"); ax.set_zlabel("Z (m)")
+        ax.legend()
+        plt.title("Sound Source Localization")
+        plt.show() if show_plots else plt.savefig("localization_result.png")
+        plt.close(fig)
+    if visualize_correlation:
+        from .plotting import plot_correlation_3d, plot_correlation_heatmap
+        plot_correlation_heatmap(corr_matrix, mic_positions, show_plot=show_plots, save_path="heatmap.png")
+        plot_correlation_3d(list(corr_rows), mic_pairs, fs, show_plot=show_plots, save_path="correlation_3d.png")
+
+    return {
+        "estimated_position": position,
+        "actual_position": source_position if use_simulation else None,
+        "mic_positions": mic_positions,
+        "correlation_metrics": correlation_metrics if analyze_correlation else None,
+        "correlation_matrix": corr_matrix if visualize_correlation else None,
+        "calibration_data": calibration_data,
+    }

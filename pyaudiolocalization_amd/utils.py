@@ -1,0 +1,310 @@
+"""Drop-in for the reference's utils.py on the hot path (citations are file:line into the reference).
+
+GPU (HIP engine): phat_correlation, get_time_delays_phat, compute_snr, compute_peak_to_peak_ratio,
+synchronize_signals_improved (the M cross-correlations), the bootstrap's PHAT calls.
+Host C++: generate_image_sources_iterative.  Host Python (3-unknown solve, scalars): the rest.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi
+from .engine import default_engine, image_sources
+from .materials import material_properties  # noqa: F401  (re-exported like the reference does)
+
+log = logging.getLogger(__name__)
+
+
+# ---------------------------------------------------------------- scalars and geometry (host)
+def speed_of_sound(temperature: float, humidity: float, pressure: float = 101.325) -> float:
+    """Linear c(T, H, P); out-of-range T / H fall back to 20 C / 50 % (utils.py:15-27)."""
+    if not -50 <= temperature <= 50:
+        log.warning("unusual temperature, using 20 C")
+        temperature = 20
+    if not 0 <= humidity <= 100:
+        log.warning("unusual humidity, using 50 %")
+        humidity = 50
+    return 331 + 0.6 * temperature + 0.0124 * humidity + 0.0006 * (pressure - 101.325)
+
+
+def reflect_point_across_plane(point: Sequence[float], plane: Sequence[float]) -> np.ndarray:
+    """Mirror image of a point in the plane a x + b y + c z + d = 0 (utils.py:29-42)."""
+    a, b, c, d = plane
+    norm2 = a ** 2 + b ** 2 + c ** 2
+    if norm2 == 0:
+        raise ValueError("invalid plane: a^2 + b^2 + c^2 is 0")
+    x, y, z = point
+    k = 2 * (a * x + b * y + c * z + d) / norm2
+    return np.array([x - a * k, y - b * k, z - c * k])
+
+
+def distance(point1: Sequence[float], point2: Sequence[float]) -> float:
+    return np.linalg.norm(np.array(point1) - np.array(point2))               # utils.py:44-48
+
+
+def calculate_attenuation(distance_val: float, material: str, frequency: float, material_properties: Dict[str, Any]) -> float:
+    """1/max(d, 0.1) * exp(-freq_coeff f d) * exp(-absorption d); unknown material -> 'air' (utils.py:50-65)."""
+    d = max(distance_val, 0.1)
+    if material not in material_properties:
+        log.warning("material '%s' undefined, using 'air'", material)
+        material = "air"
+    row = material_properties[material]
+    return (1 / d) * np.exp(-row["freq"] * frequency * d) * np.exp(-row["absorption"] * d)
+
+
+def generate_image_sources_iterative(source, planes, max_order, frequency, material_properties, mic_positions,
+                                     absorption_threshold: float = 0.01, round_decimals: int = 6) -> List[Dict[str, Any]]:
+    """Breadth-first image-source search with rounding de-dup and attenuation pruning
+    (utils.py:67-106) in the engine's host C++ (pal_image_sources)."""
+    names = list(material_properties.keys())
+    ids = []
+    for pl in planes:
+        mat = pl.get("material", "air")
+        complete = mat in material_properties and "absorption" in material_properties[mat] and "freq" in material_properties[mat]
+        ids.append(names.index(mat) if complete else -1)
+    absorption = [material_properties[n].get("absorption", np.nan) for n in names]
+    freq_coeff = [material_properties[n].get("freq", np.nan) for n in names]
+    plane_rows = np.array([pl["plane"] for pl in planes], dtype=np.float64).reshape(-1, 4)
+    try:
+        img, mat = image_sources(source, plane_rows, ids, absorption, freq_coeff, max_order, frequency,
+                                 np.asarray(mic_positions, dtype=np.float64), absorption_threshold, round_decimals)
+    except KeyError as exc:                                                   # utils.py:93-96
+        name = planes[int(exc.args[0])].get("material", "air")
+        if name not in material_properties:
+            raise ValueError(f"material '{name}' is not defined; add it to the material table") from None
+        raise ValueError(f"absorption or frequency property missing for material '{name}'") from None
+    return [{"source": img[k].copy(), "material": names[mat[k]]} for k in range(img.shape[0])]
+
+
+# ---------------------------------------------------------------- PHAT correlation and TDOA (GPU)
+def phat_correlation(sig1: np.ndarray, sig2: np.ndarray) -> np.ndarray:
+    """Unshifted PHAT sequence on the exact n = n1 + n2 - 1 grid (utils.py:108-119)."""
+    return default_engine().phat_correlation(sig1, sig2)
+
+
+_WARNINGS = (
+    (_ffi.BR_ALT_THRESHOLD, "no peaks with the primary threshold, trying mean(|corr|)"),
+    (_ffi.BR_ARGMAX_NO_PEAKS, "no peaks with the alternative threshold either, using the correlation maximum"),
+    (_ffi.BR_WINDOW_RETRY, "no peaks inside the expected delay range, trying mean(|corr|)"),
+    (_ffi.BR_ARGMAX_WINDOW, "no valid peaks after the alternative filtering, using the correlation maximum"),
+)
+
+
+def get_time_delays_phat(sig1: np.ndarray, sig2: np.ndarray, fs: float, num_peaks: int = 1,
+                         threshold_method: str = "median", threshold_multiplier: float = 1.0,
+                         max_expected_delay: Optional[float] = None) -> Tuple[List[float], np.ndarray, np.ndarray]:
+    """(time delays of the selected peaks, corr, lags in seconds) exactly like utils.py:121-181,
+    including the un-shifted lag mapping and the whole fallback chain (Q4)."""
+    n1, n2 = len(sig1), len(sig2)
+    ks, rec, corr = default_engine().get_time_delays_phat(sig1, sig2, fs, num_peaks, threshold_method,
+                                                          threshold_multiplier, max_expected_delay, want_corr=True)
+    for bit, text in _WARNINGS:
+        if int(rec["branch"]) & bit:
+            log.warning(text)
+    time_lags = np.arange(-(n2 - 1), n1) / fs                                 # correlation_lags(...)/fs (utils.py:141-142)
+    return list(time_lags[ks]), corr, time_lags
+
+
+def compute_peak_to_peak_ratio(corr: np.ndarray) -> float:
+    rec = default_engine().corr_metrics(corr)                                 # utils.py:228-236
+    return np.inf if rec["cmin"] == 0 else rec["cmax"] / abs(rec["cmin"])
+
+
+def compute_snr(corr: np.ndarray) -> float:
+    return float(default_engine().corr_metrics(corr)["snr"])                  # utils.py:238-250
+
+
+# ---------------------------------------------------------------- significance (next row N1)
+def bootstrap_significance(sig1: np.ndarray, sig2: np.ndarray, fs: float, num_bootstrap: int = 1000, alpha: float = 0.05,
+                           bootstrap_mode: str = "permutation", block_size: int = 50) -> float:
+    """(1 - alpha) percentile of max(PHAT(sig1, shuffled sig2)) (utils.py:183-216); the PHAT maxima
+    come from the engine, the shuffles from the global NumPy RNG like the reference."""
+    eng = default_engine()
+    sig2 = np.asarray(sig2)
+    peaks = []
+    for _ in range(num_bootstrap):
+        if bootstrap_mode == "permutation":
+            other = np.random.permutation(sig2)
+        elif bootstrap_mode == "block":
+            blocks = [sig2[i:i + block_size] for i in range(0, len(sig2), block_size)]
+            np.random.shuffle(blocks)
+            other = np.concatenate(blocks)[: len(sig2)]
+        elif bootstrap_mode == "circular":
+            other = np.roll(sig2, np.random.randint(0, len(sig2)))
+        else:
+            raise ValueError("unknown bootstrap_mode; use 'permutation', 'block' or 'circular'")
+        _, rec, _ = eng.get_time_delays_phat(sig1, other, fs, want_corr=False)
+        peaks.append(rec["cmax"])
+    return np.percentile(peaks, 100 * (1 - alpha))
+
+
+def perform_significance_test_bootstrap(sig1, sig2, fs, alpha: float = 0.05) -> Tuple[float, bool]:
+    _, rec, _ = default_engine().get_time_delays_phat(sig1, sig2, fs, want_corr=False)
+    peak = rec["cmax"]
+    return peak, peak > bootstrap_significance(sig1, sig2, fs, alpha=alpha)    # utils.py:218-226
+
+
+def perform_significance_test(corr, sig1, sig2, fs, alpha: float = 0.05, snr_threshold: float = 2.0) -> Tuple[float, bool]:
+    snr = compute_snr(corr)
+    _, ok = perform_significance_test_bootstrap(sig1, sig2, fs, alpha=alpha)
+    return snr, ok and snr > snr_threshold                                      # utils.py:252-259
+
+
+def compute_cross_correlation_metrics(corr, sig1, sig2, fs, alpha: float = 0.05) -> Dict[str, Any]:
+    ratio = compute_peak_to_peak_ratio(corr)
+    snr, significant = perform_significance_test(corr, sig1, sig2, fs, alpha=alpha)
+    return {"peak_to_peak_ratio": ratio, "snr": snr, "significant": significant}   # utils.py:261-271
+
+
+# ---------------------------------------------------------------- TDOA -> position (host, 3 unknowns)
+def determine_optimal_number_of_clusters(data, max_clusters: int = 5, method: str = "kmeans", eps: float = 0.001,
+                                         min_samples: int = 2) -> int:
+    """Silhouette-best k for KMeans, or DBSCAN's cluster count when its silhouette is positive (utils.py:273-302)."""
+    from sklearn.cluster import DBSCAN, KMeans
+    from sklearn.metrics import silhouette_score
+    pts = np.array(data)
+    if len(pts) < 2:
+        return 1
+    if method == "kmeans":
+        best, best_k = -1, 1
+        for k in range(2, min(max_clusters, len(pts)) + 1):
+            score = silhouette_score(pts, KMeans(n_clusters=k, random_state=0).fit(pts).labels_)
+            if score > best:
+                best, best_k = score, k
+        return best_k
+    if method == "dbscan":
+        labels = DBSCAN(eps=eps, min_samples=min_samples).fit(pts).labels_
+        core = labels != -1
+        if core.sum() < 2:
+            return 1
+        return len(set(labels[core])) if silhouette_score(pts[core], labels[core]) > 0 else 1
+    raise ValueError("unknown clustering method; available: 'kmeans', 'dbscan'")
+
+
+def heuristic_initialization_adaptive(mic_positions, mic_pairs, tdoas, c, clustering_method: str = "kmeans",
+                                      eps: float = 0.001, min_samples: int = 2) -> List[List[float]]:
+    """Per-pair points on the mic axis offset by c|td|/2 from the midpoint, clustered into start
+    positions; the array centroid is always among the guesses (utils.py:304-362)."""
+    from sklearn.cluster import DBSCAN, KMeans
+    mics = np.array(mic_positions)
+    centroid = np.mean(mics, axis=0)
+    if np.size(tdoas) == 0:
+        return [centroid.tolist()]
+    points = []
+    for (i, j), td in zip(mic_pairs, np.array(tdoas)):
+        a, b = np.array(mic_positions[i]), np.array(mic_positions[j])
+        axis = b - a
+        length = np.linalg.norm(axis)
+        if length == 0:
+            continue
+        shift = (c * abs(td)) / 2 * (axis / length)
+        points.append(((a + b) / 2 - shift if td > 0 else (a + b) / 2 + shift).tolist())
+    if not points:
+        return [centroid.tolist()]
+    if clustering_method == "kmeans":
+        k = determine_optimal_number_of_clusters(points, method=clustering_method, eps=eps, min_samples=min_samples)
+        guesses = KMeans(n_clusters=k, random_state=0).fit(points).cluster_centers_.tolist()
+    elif clustering_method == "dbscan":
+        labels = DBSCAN(eps=eps, min_samples=min_samples).fit(points).labels_
+        guesses = [np.mean([p for p, l in zip(points, labels) if l == lab], axis=0).tolist()
+                   for lab in set(labels) - {-1}]
+        if not guesses:
+            guesses = [centroid.tolist()]
+    else:
+        guesses = [centroid.tolist()]
+    if not any(np.allclose(centroid, g, atol=1e-6) for g in guesses):
+        guesses.append(centroid.tolist())
+    return guesses
+
+
+def dynamic_bounds_extended(mic_positions, tdoas, c, buffer: float = 5.0) -> List[Tuple[float, float]]:
+    """Array bounding box grown by buffer + max(1, 75th percentile of c|td|) (utils.py:364-382)."""
+    mics = np.array(mic_positions)
+    extra = max(np.percentile(c * np.abs(np.array(tdoas)), 75), 1.0) if np.size(tdoas) > 0 else 0.0
+    lo = np.min(mics, axis=0) - (buffer + extra)
+    hi = np.max(mics, axis=0) + (buffer + extra)
+    dims = mics.shape[1] if mics.ndim > 1 else 1
+    return [(lo[i], hi[i]) for i in range(dims)]
+
+
+def equations(vars, mic_positions, mic_pairs, tdoas, c, weights: Optional[np.ndarray] = None) -> List[float]:
+    """Weighted range-difference residuals (d_j - d_i) - c td (utils.py:384-405)."""
+    if weights is not None and len(weights) != len(mic_pairs):
+        raise ValueError("length of weights must equal the number of mic pairs")
+    src = np.array(vars)
+    out = []
+    for k, ((i, j), td) in enumerate(zip(mic_pairs, tdoas)):
+        r = (np.linalg.norm(src - np.array(mic_positions[j])) - np.linalg.norm(src - np.array(mic_positions[i]))) - c * td
+        if weights is not None:
+            r *= weights[k]
+        out.append(r)
+    return out
+
+
+def compute_weights(correlation_metrics, mic_pairs) -> np.ndarray:
+    """SNR per pair (1.0 when missing), normalised to mean 1 (utils.py:484-497)."""
+    w = np.array([1.0 if correlation_metrics.get(p) is None else correlation_metrics[p].get("snr", 1.0) for p in mic_pairs])
+    return w / np.mean(w) if np.mean(w) != 0 else w
+
+
+# ---------------------------------------------------------------- synchronisation (GPU correlations)
+def synchronize_signals_improved(signals: List[np.ndarray], fs: float, use_interpolation: bool = True) -> List[np.ndarray]:
+    """Align every signal to the highest-energy one (utils.py:407-457).  The M full cross-correlations
+    and their argmax run on the engine; the 5-point spline refinement and zero padding are host work."""
+    from scipy.interpolate import CubicSpline
+    if len({len(s) for s in signals}) != 1:
+        raise ValueError("the engine synchronises equal-length signals (simulated frames always are)")
+    rows = np.asarray(signals, dtype=np.float64)
+    energies = [np.sum(np.asarray(s) ** 2) for s in signals]
+    ref_idx = int(np.argmax(energies))
+    kpk, win, pkabs, ref_peak = default_engine().xcorr_vs_ref(rows, ref_idx)
+    n = rows.shape[1]
+    limit = int(fs * 0.05)
+    shifts: List[float] = []
+    for idx in range(rows.shape[0]):
+        if idx == ref_idx:
+            shifts.append(0)
+            continue
+        pk = int(kpk[idx])
+        refined = pk
+        if pkabs[idx] < 0.3 * ref_peak:
+            log.warning("low correlation peak for signal %d during synchronisation", idx)   # shift is NOT zeroed
+        elif use_interpolation and 1 < pk < 2 * n - 3:
+            fine = np.linspace(pk - 2, pk + 2, 100)
+            refined = fine[np.argmax(np.abs(CubicSpline(np.arange(pk - 2, pk + 3), win[idx])(fine)))]
+        shift = refined - (n - 1)
+        if abs(shift) > limit:
+            log.warning("shift of %s samples for signal %d is implausible, using 0", shift, idx)
+            shift = 0
+        shifts.append(shift)
+    lowest = min(shifts)
+    padded = [np.pad(np.asarray(s, dtype=np.float64), (max(0, int(round(sh - lowest))), 0)) for s, sh in zip(signals, shifts)]
+    length = max(len(p) for p in padded)
+    return [np.pad(p, (0, length - len(p))) for p in padded]
+
+
+def read_audio_files(audio_files: List[str], expected_fs: float) -> List[np.ndarray]:
+    """Real-audio ingest (utils.py:459-482): outside the hot path; needs the optional
+    soundfile / resampy packages, which the build image does not have."""
+    from .signal_processing import dynamic_range_compression, normalize_signal, resample_audio
+    out = []
+    for path in audio_files:
+        if not os.path.isfile(path):
+            log.error("audio file not found: %s", path)
+            raise FileNotFoundError(f"audio file not found: {path}")
+        try:
+            import soundfile  # noqa: PLC0415 - optional dependency
+            data, fs = soundfile.read(path)
+            if data.ndim > 1:
+                data = np.mean(data, axis=1)
+            if fs != expected_fs:
+                data = resample_audio(data, fs, expected_fs)
+            out.append(dynamic_range_compression(normalize_signal(data)))
+        except Exception as exc:
+            log.error("error reading audio file '%s': %s", path, exc)
+            raise RuntimeError(f"error reading audio file '{path}': {exc}")
+    return out

@@ -1,0 +1,37 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an AMD GPU (runs the HIP engine through the C ABI)")
+    lib = os.path.join(ROOT, "pyaudiolocalization_amd", "libpal_hip.so")
+    if not os.path.exists(lib):          # fresh checkout: build once (hipcc cross-compiles without a GPU)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "pyaudiolocalization_amd", "csrc"), "-j", "4"], check=True)
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One HIP engine for the GPU tests; creation fails loudly when no GPU is visible."""
+    from pyaudiolocalization_amd import Engine
+    eng = Engine(0)
+    yield eng
+    eng.close()

@@ -1,0 +1,169 @@
+"""Shared scaffolding for the parity tests: the reference's stage sequence main.py:165-228
+(simulate -> synchronise -> prefilter -> pair table), run stage by stage.
+
+IMPORTANT ("conditioning of the reference"): the reference prefilters with a 10th-order
+Butterworth band-pass in transfer-function form (signal_processing.py:127-128).  That recurrence
+amplifies a 1e-16 relative change of its INPUT into 2e-6 (44.1/48 kHz) .. 5e-3 (96 kHz) of its
+OUTPUT, and PHAT whitening then turns the stop-band rounding noise into unit-magnitude bins.  Two
+implementations whose simulated signals agree to 1e-15 therefore produce different TDOA tables -
+including the reference against itself on another NumPy build.  Parity is consequently asserted
+stage by stage with every stage fed the bit-identical input the reference saw (the oracle's
+previous stage, which is pinned to the reference's fixtures bit for bit):
+    simulate   : |x - ref| <= 1e-11        (different FFT, well-conditioned stage)
+    synchronise: identical integer pads -> bit-identical rows
+    prefilter  : bit-identical (same operation order, no fused multiply-add)
+    pair table : bit-identical selected indices, float metrics to 1e-9
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import cases
+from oracle import pal_oracle as O
+
+
+def tag_of(med):
+    return "none" if med is None else ("%g" % med).replace(".", "p")
+
+
+def geometry(source, mics, fs, duration, freq, planes, table, max_reflections=3, thr=0.01):
+    delays, gains, longest, _ = O.multipath_paths(source, mics, cases.C_SOUND, freq, planes, table, max_reflections, thr)
+    return delays, gains, int((duration + longest) * fs), int(duration * fs)
+
+
+class OracleImpl:
+    name = "oracle"
+
+    def simulate(self, base, delays, gains, fs, total, trim):
+        # path-by-path loop: bit-identical to the reference (the fused form differs by ~1e-15)
+        return O.simulate_literal(base, delays, gains, fs, total, trim)
+
+    def synchronize(self, signals, fs):
+        return np.array(O.synchronize_signals(list(signals), fs))
+
+    def prefilter(self, rows, fs):
+        return np.array([O.noise_reduction(r, fs) for r in rows])
+
+    def pair_table(self, rows, fs, med, pair_idx=None):
+        m = rows.shape[0]
+        pairs = [(i, j) for i in range(m) for j in range(i + 1, m)]
+        if pair_idx is not None:
+            pairs = [pairs[k] for k in pair_idx]
+        recs = [O.pair_record(O.phat_correlation(rows[i], rows[j]), rows.shape[1], fs, max_expected_delay=med) for i, j in pairs]
+        return {k: np.array([r[k] for r in recs]) for k in recs[0]}
+
+
+class EngineImpl:
+    """Product path: drop-in modules -> ctypes -> libpal_hip.so -> HIP kernels."""
+    name = "hip"
+
+    def simulate(self, base, delays, gains, fs, total, trim):
+        from pyaudiolocalization_amd import default_engine
+        return default_engine().simulate_multipath(base[None], fs, total, delays[None], gains[None], trim)[0]
+
+    def synchronize(self, signals, fs):
+        from pyaudiolocalization_amd.utils import synchronize_signals_improved
+        return np.array(synchronize_signals_improved(list(signals), fs))
+
+    def prefilter(self, rows, fs):
+        from pyaudiolocalization_amd.signal_processing import noise_reduction_rows
+        return noise_reduction_rows(rows, fs, "butterworth")
+
+    def pair_table(self, rows, fs, med, pair_idx=None):
+        from pyaudiolocalization_amd.main import tdoa_table
+        t = tdoa_table(rows, fs, med)
+        if pair_idx is not None:
+            t = t[np.asarray(pair_idx)]
+        return {k: t[k] for k in ("k_sel", "branch", "k_argmax", "cmax", "cmin", "snr")}
+
+
+def digest_close(got_rows, want_digest, tol):
+    """Compare waveforms with the reference's stored fingerprints (length, sum, sum of squares, max, 64 samples)."""
+    got = np.array([cases.waveform_digest(r) for r in got_rows])
+    assert got.shape == want_digest.shape, (got.shape, want_digest.shape)
+    assert np.array_equal(got[:, 0], want_digest[:, 0]), "lengths differ"
+    scale = np.maximum(1.0, np.abs(want_digest))
+    err = np.max(np.abs(got - want_digest) / scale)
+    assert err <= tol, f"waveform digest differs by {err:.3e} (allowed {tol:.1e})"
+
+
+def check_table(got, gold, tag, pair_idx=None, *, exact_values=False):
+    """Bit-exact integer indices; float metrics to 1e-9 relative (1e-12 when the producer shares the
+    reference's FFT, i.e. the oracle)."""
+    sel = slice(None) if pair_idx is None else np.asarray(pair_idx)
+    want_k = gold[f"k_sel_{tag}"][sel]
+    assert np.array_equal(got["k_argmax"], gold[f"k_argmax_{tag}"][sel]), "argmax index differs"
+    bad = np.flatnonzero(got["k_sel"] != want_k)
+    assert bad.size == 0, (f"selected index differs for {bad.size}/{want_k.size} pairs: rows {bad[:8]} "
+                           f"got {got['k_sel'][bad[:8]]} want {want_k[bad[:8]]}")
+    rtol = 1e-12 if exact_values else 1e-9
+    for key in ("cmax", "cmin", "snr"):
+        w = gold[f"{key}_{tag}"][sel]
+        assert np.allclose(got[key], w, rtol=rtol, atol=1e-15), f"{key}: max rel err {np.max(np.abs(got[key] - w) / np.abs(w)):.3e}"
+
+
+def run_chain(impl, gold, prefix, base, delays, gains, fs, total, trim, meds, pair_idx=None):
+    """Stage-by-stage parity of `impl` against the reference fixtures, teacher-forced (module docstring)."""
+    oracle = OracleImpl()
+    is_oracle = impl.name == "oracle"
+    g = {k[len(prefix):]: v for k, v in gold.items() if k.startswith(prefix)}
+    sim_o = oracle.simulate(base, delays, gains, fs, total, trim)
+    digest_close(sim_o, g["sim_digest"], 1e-13)
+    if not is_oracle:
+        sim_i = impl.simulate(base, delays, gains, fs, total, trim)
+        assert sim_i.shape == sim_o.shape
+        assert np.max(np.abs(sim_i - sim_o)) <= 1e-11, f"simulate: max abs err {np.max(np.abs(sim_i - sim_o)):.3e}"
+    sync_o = oracle.synchronize(sim_o, fs)
+    assert sync_o.shape[1] == int(g["L"][0])
+    digest_close(sync_o, g["sync_digest"], 1e-13)
+    if not is_oracle:
+        sync_i = impl.synchronize(sim_o, fs)
+        assert sync_i.shape == sync_o.shape and np.array_equal(sync_i, sync_o), "synchronise: pads differ"
+    filt_o = oracle.prefilter(sync_o, fs)
+    digest_close(filt_o, g["filt_digest"], 1e-13)
+    if not is_oracle:
+        filt_i = impl.prefilter(sync_o, fs)
+        assert np.array_equal(filt_i, filt_o), f"prefilter not bit-identical: max abs err {np.max(np.abs(filt_i - filt_o)):.3e}"
+    for med in meds:
+        got = impl.pair_table(filt_o, fs, med, pair_idx)
+        check_table(got, g, tag_of(med), pair_idx, exact_values=is_oracle)
+        if not is_oracle:       # branch codes are not part of the reference's return value: compare with the oracle
+            npairs = filt_o.shape[0] * (filt_o.shape[0] - 1) // 2
+            sub = np.arange(npairs)[:48] if pair_idx is None else np.asarray(pair_idx)[:48]
+            want = oracle.pair_table(filt_o, fs, med, sub)
+            assert np.array_equal(got["branch"][: sub.size], want["branch"]), "fallback branch codes differ"
+    return filt_o
+
+
+# ---------------------------------------------------------------- per-config inputs (base, delays, gains, fs, total, trim)
+def _pack(base, geo, fs):
+    delays, gains, total, trim = geo
+    return base, delays, gains, fs, total, trim
+
+
+def c1_case():
+    cfg = cases.c1_config()
+    return _pack(O.generate_signal("sine", cfg["fs"], 1.0, 1000),
+                 geometry(cfg["source_position"], np.array(cfg["mic_positions"]), cfg["fs"], 1.0, 1000,
+                          cfg["reflective_planes"], O.MATERIALS_DEFAULT), cfg["fs"])
+
+
+def c2_case(low_loss):
+    cfg = cases.c2_config()
+    table = cases.LOW_LOSS if low_loss else O.MATERIALS_DEFAULT
+    return _pack(O.generate_signal("chirp", 48000, 1.0, 500),
+                 geometry(cfg["source_position"], np.array(cfg["mic_positions"]), 48000, 1.0, 500, cfg["reflective_planes"],
+                          table), 48000)
+
+
+def c3_case(trial=0):
+    cfg = cases.c3_config(trial)
+    return _pack(cases.c3_base(trial),
+                 geometry(cfg["source_position"], np.array(cfg["mic_positions"]), 48000, 0.5, 1000, [], O.MATERIALS_DEFAULT),
+                 48000)
+
+
+def c5_case(frame):
+    return _pack(cases.c5_base(frame),
+                 geometry(cases.c5_source(frame), cases.grid_array_64(), 48000, 0.25, 1000, cases.DEFAULT_PLANES,
+                          cases.LOW_LOSS), 48000)

@@ -1,0 +1,130 @@
+"""Pins the NumPy oracle to the fixtures captured from the unmodified reference
+(oracle/make_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import cases
+from oracle import pal_oracle as O
+
+import stages
+from stages import OracleImpl, check_table, digest_close, tag_of
+
+IMPL = OracleImpl()
+
+
+def test_selection_edge_cases(golden):
+    rows = golden("selection_edges.npz")["rows"]
+    todo = cases.selection_edge_cases()
+    assert len(todo) == rows.shape[0]
+    branches = set()
+    for case, want in zip(todo, rows):
+        assert case["t"] == int(want[0])
+        corr = O.phat_correlation(case["a"], case["b"])
+        ks, br = O.select_peaks(corr, len(case["b"]), case["fs"], 1, case["method"], case["mult"], case["med"])
+        branches.add(br)
+        assert int(ks[0]) == int(want[1]), (case["t"], int(ks[0]), int(want[1]), br)
+        assert np.max(corr) == want[2] and np.min(corr) == want[3] and int(np.argmax(corr)) == int(want[4])
+        assert O.compute_snr(corr) == want[5]
+        assert O.compute_peak_to_peak_ratio(corr) == want[6]
+    # the fixture exercises the whole fallback chain
+    assert {0, 1, 3, 4, 12, 13}.issubset(branches), branches
+
+
+def test_find_peaks_restatement_against_scipy():
+    from scipy.signal import find_peaks
+    rng = np.random.default_rng(5)
+    for t in range(200):
+        x = rng.standard_normal(int(rng.integers(5, 300)))
+        if t % 4 == 0:
+            x[rng.integers(0, x.size, 10)] = 0.5        # plateaus without tying peak heights elsewhere
+        h, d = float(rng.uniform(-1, 1)), int(rng.integers(1, 12))
+        want, _ = find_peaks(x, height=h, distance=d)
+        got, _ = O.find_peaks_height_distance(x, h, d)
+        if np.unique(x[O.local_maxima(x)]).size == O.local_maxima(x).size:   # exact height ties are unpinned
+            assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        O.find_peaks_height_distance(np.zeros(10), 0.0, 0)
+
+
+def test_filters_and_delay(golden):
+    g = golden("filters.npz")
+    x = np.random.default_rng(21).standard_normal(4000)
+    for fs in (44100, 48000, 96000):
+        assert np.array_equal(O.noise_reduction(x, fs), g[f"butter_{fs}"])
+    assert np.allclose(O.noise_reduction(x, 48000, "fir"), g["fir_48000"], rtol=0, atol=1e-14)
+    assert np.array_equal(O.noise_reduction(x, 48000, "wiener"), g["wiener"])
+    assert np.array_equal(O.fractional_delay(x, 0.00123, 48000), g["fracdelay"])
+    assert np.array_equal(O.dynamic_range_compression(x), g["compress"])
+    with pytest.raises(ValueError):
+        O.noise_reduction(x, 48000, "nope")
+    with pytest.raises(ValueError):
+        O.filtfilt(*O.butter_bandpass(48000), x[:30])
+
+
+def test_image_sources(golden):
+    g = golden("image_sources.npz")
+    mics = np.random.default_rng(2).uniform(-0.5, 0.5, (8, 3))
+    for order, count in ((1, 6), (2, 24), (3, 62)):
+        imgs = O.image_sources([1.0, 2.0, 0.5], cases.SHOEBOX, order, 500, cases.LOW_LOSS, mics, 0.01)
+        assert len(imgs) == g[f"shoebox_o{order}"].shape[0]
+        assert np.array_equal(np.array([i["source"] for i in imgs]), g[f"shoebox_o{order}"])
+        assert [i["material"] for i in imgs] == list(g[f"shoebox_o{order}_mat"])
+    for f in (0.01, 0.1, 0.25, 1.0):
+        imgs = O.image_sources([1.0, 2.0, 0.5], cases.DEFAULT_PLANES, 3, f, O.MATERIALS_DEFAULT, mics, 0.01)
+        want = g["default_f%s" % str(f).replace(".", "p")]
+        assert np.array_equal(np.array([i["source"] for i in imgs]).reshape(-1, 3), want)
+    with pytest.raises(ValueError):
+        O.image_sources([0, 0, 0], [{"plane": [0, 0, 0, 1], "material": "air"}], 1, 1.0, O.MATERIALS_DEFAULT, mics)
+    with pytest.raises(ValueError):
+        O.image_sources([0, 0, 0], [{"plane": [1, 0, 0, 1], "material": "glass"}], 1, 0.0, O.MATERIALS_DEFAULT, mics)
+
+
+def test_fused_simulation_matches_the_path_loop():
+    """sum_p a_p delay_p(x) == fade * Re IFFT(X sum_p a_p exp(-j 2 pi f tau_p)) to rounding."""
+    base, delays, gains, fs, total, trim = stages.c2_case(True)
+    base, delays, gains = base[::6][:6000], delays[:3], gains[:3]
+    fused = O.simulate_from_base(base, delays, gains, 8000, 6400, 6000)
+    loop = O.simulate_literal(base, delays, gains, 8000, 6400, 6000)
+    assert np.max(np.abs(fused - loop)) < 1e-13
+
+
+def test_c1_example1(golden):
+    g = golden("c1_example1.npz")
+    stages.run_chain(IMPL, g, "", *stages.c1_case(), (0.05, None))
+    assert np.array_equal(g["k_sel_0p05"], np.full(6, 44098))       # lag -1 for all six pairs
+    assert np.allclose(g["position"], [0.50341234, 0.50680951, 0.51019149], atol=1e-8)
+
+
+def test_c2_chirp8(golden):
+    g = golden("c2_chirp8.npz")
+    assert g["a_images"].shape[0] == 0 and g["b_images"].shape[0] == 7
+    for tag, low in (("a_", False), ("b_", True)):
+        stages.run_chain(IMPL, g, tag, *stages.c2_case(low), (0.05, None))
+
+
+def test_c3_grid64_subset(golden):
+    g = golden("c3_grid64_trial0.npz")
+    stages.run_chain(IMPL, g, "", *stages.c3_case(0), (0.05,), pair_idx=np.arange(0, 2016, 29))
+
+
+def test_c4_sphere_first12(golden):
+    g = golden("c4_sphere_first12.npz")
+    frames = cases.c4_frames(12)
+    digest_close(frames, g["frames_digest"], 1e-12)
+    idx = np.arange(0, 66, 3)
+    for med in (0.05, None):
+        check_table(IMPL.pair_table(frames, 96000, med, idx), g, tag_of(med), idx, exact_values=True)
+
+
+def test_c5_stream_frames(golden):
+    g = golden("c5_stream_frames01.npz")
+    for f in (0, 1):
+        stages.run_chain(IMPL, g, f"f{f}_", *stages.c5_case(f), (0.05,), pair_idx=np.arange(0, 2016, 41))
+
+
+def test_metric_frames_first8(golden):
+    g = golden("metric_44k1_first8.npz")
+    frames = cases.metric_frames(1, 8)[0]
+    idx = np.arange(0, 28, 2)
+    for med in (0.05, None):
+        check_table(IMPL.pair_table(frames, 44100, med, idx), g, tag_of(med), idx, exact_values=True)
