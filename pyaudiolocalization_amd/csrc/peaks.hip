@@ -26,7 +26,7 @@ namespace pal {
 namespace {
 
 constexpr int kCap = 2048;      // in-LDS rank-search capacity
-constexpr int kMemo = 128;      // resolved peaks remembered per selection
+constexpr int kMemo = 1024;     // resolved peaks remembered per selection
 constexpr int kStack = 64;      // depth of the suppression recursion
 
 struct PeakArgs {

@@ -322,7 +322,20 @@ int pal_simulate_multipath(pal_handle h, const double* base, int B, int nbase, d
     if ((rc = e->scratch(6, size_t(rows) * out_len * sizeof(double), &dout)) != PAL_OK) break;
     if ((rc = e->check(hipMemcpyAsync(db, base, size_t(B) * nbase * sizeof(double), hipMemcpyHostToDevice, e->stream), "upload")) != PAL_OK) break;
     if ((rc = e->check(hipMemcpyAsync(dd, delays, size_t(rows) * K * sizeof(double), hipMemcpyHostToDevice, e->stream), "upload")) != PAL_OK) break;
-    if ((rc = e->check(hipMemcpyAsync(dg, gains, size_t(rows) * K * sizeof(double), hipMemcpyHostToDevice, e->stream), "upload")) != PAL_OK) break;
+    // Per-mic power-of-two rescale: path gains reach 1e-63 and two mics share one complex
+    // transform, so a mic 1e16 times weaker than its partner would drown in the partner's rounding
+    // error.  Scaling a row by 2^-e is exact and cancels bit for bit in normalize_signal (x / max|x|).
+    std::vector<double> scaled(gains, gains + size_t(rows) * K);
+    for (int r = 0; r < rows; ++r) {
+      double top = 0;
+      for (int p = 0; p < K; ++p) top = std::fmax(top, std::fabs(scaled[size_t(r) * K + p]));
+      if (top > 0 && std::isfinite(top)) {
+        const int ex = std::ilogb(top);
+        for (int p = 0; p < K; ++p) scaled[size_t(r) * K + p] = std::ldexp(scaled[size_t(r) * K + p], -ex);
+      }
+    }
+    if ((rc = e->check(hipMemcpyAsync(dg, scaled.data(), size_t(rows) * K * sizeof(double), hipMemcpyHostToDevice, e->stream), "upload")) != PAL_OK) break;
+    if ((rc = e->check(hipStreamSynchronize(e->stream), "upload sync")) != PAL_OK) break;
     rc = simulate_dev(e, static_cast<double*>(db), B, nbase, fs, N, static_cast<double*>(dd), static_cast<double*>(dg), rows, M,
                       K, out_len, true, true, static_cast<double*>(dout));
     if (rc != PAL_OK) break;
