@@ -42,7 +42,10 @@ struct ProfileSlot {
 
 struct Engine {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;    // FFT passes, copies, everything a caller can order against
+  hipStream_t stream2 = nullptr;   // peak selection of launch group g while the passes of g+1 run on `stream`
+  hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams
+  bool overlap = true;
   std::string err;
   int chunk = 32;                               // transforms per launch group
   std::map<std::tuple<int, int, int>, Plan> plans;   // (n, lin, nout) -> plan
@@ -74,8 +77,8 @@ struct Engine {
   int build_conv(Conv& c, const cd* w, int n, int neg_count, int pos_count, bool conj_kernel, double extra_scale);
   // profiling helpers
   int prof_slot(const char* name);
-  void prof_begin(int slot, hipEvent_t* a);
-  void prof_end(int slot, hipEvent_t a);
+  void prof_begin(int slot, hipEvent_t* a, hipStream_t on);
+  void prof_end(int slot, hipEvent_t a, hipStream_t on);
   void prof_flush();
 
   // pipelines (all pointers are device pointers)
@@ -83,21 +86,22 @@ struct Engine {
   int pair_correlations(Plan& pl, const cd* spectra, const int4* quads, int64_t npairs, int n2,
                         const pal_phat_params& prm, pal_pair_record* table, int32_t* ksel_multi, double* corr_out);
   int peaks(const double* corr, size_t stride, int rows, int n, int n2, const pal_phat_params& prm,
-            pal_pair_record* table, int32_t* ksel_multi);
+            pal_pair_record* table, int32_t* ksel_multi, hipStream_t on);
 };
 
 struct ProfScope {
   Engine* e;
   int slot;
   hipEvent_t a = nullptr;
-  ProfScope(Engine* eng, const char* name) : e(eng), slot(-1) {
+  hipStream_t on;
+  ProfScope(Engine* eng, const char* name, hipStream_t s = nullptr) : e(eng), slot(-1), on(s ? s : eng->stream) {
     if (e->profiling) {
       slot = e->prof_slot(name);
-      e->prof_begin(slot, &a);
+      e->prof_begin(slot, &a, on);
     }
   }
   ~ProfScope() {
-    if (slot >= 0) e->prof_end(slot, a);
+    if (slot >= 0) e->prof_end(slot, a, on);
   }
 };
 

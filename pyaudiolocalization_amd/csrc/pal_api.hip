@@ -61,19 +61,20 @@ static hipEvent_t take_event(Engine* e) {
   return e->ev_pool[e->ev_used++];
 }
 
-void Engine::prof_begin(int, hipEvent_t* a) {
+void Engine::prof_begin(int, hipEvent_t* a, hipStream_t on) {
   if (pending.size() >= 16384) {
     hipStreamSynchronize(stream);
+    hipStreamSynchronize(stream2);
     prof_flush();
   }
   *a = take_event(this);
-  if (*a) hipEventRecord(*a, stream);
+  if (*a) hipEventRecord(*a, on);
 }
 
-void Engine::prof_end(int slot, hipEvent_t a) {
+void Engine::prof_end(int slot, hipEvent_t a, hipStream_t on) {
   hipEvent_t b = take_event(this);
   if (!a || !b) return;
-  hipEventRecord(b, stream);
+  hipEventRecord(b, on);
   pending.push_back({slot, a, b});
 }
 
@@ -176,13 +177,20 @@ int pal_create(int device, pal_handle* out) {
   }
   Engine* e = new Engine();
   e->device = device;
-  if ((rc = hipSetDevice(device)) != hipSuccess || (rc = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) {
+  if ((rc = hipSetDevice(device)) != hipSuccess || (rc = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (rc = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking)) != hipSuccess ||
+      (rc = hipEventCreateWithFlags(&e->ev_corr[0], hipEventDisableTiming)) != hipSuccess ||
+      (rc = hipEventCreateWithFlags(&e->ev_corr[1], hipEventDisableTiming)) != hipSuccess ||
+      (rc = hipEventCreateWithFlags(&e->ev_peaks[0], hipEventDisableTiming)) != hipSuccess ||
+      (rc = hipEventCreateWithFlags(&e->ev_peaks[1], hipEventDisableTiming)) != hipSuccess) {
     g_create_error = std::string("device init: ") + hipGetErrorString(rc);
     delete e;
     return PAL_ERR_HIP;
   }
   const char* env = getenv("PAL_CHUNK");
   if (env && atoi(env) > 0) e->chunk = atoi(env);
+  env = getenv("PAL_OVERLAP");
+  if (env) e->overlap = atoi(env) != 0;
   *out = reinterpret_cast<pal_handle>(e);
   return PAL_OK;
 }
@@ -202,6 +210,8 @@ void pal_destroy(pal_handle h) {
   for (void* p : e->ws) if (p) hipFree(p);
   if (e->quads) hipFree(e->quads);
   for (hipEvent_t ev : e->ev_pool) hipEventDestroy(ev);
+  for (int k = 0; k < 2; ++k) { hipEventDestroy(e->ev_corr[k]); hipEventDestroy(e->ev_peaks[k]); }
+  hipStreamDestroy(e->stream2);
   hipStreamDestroy(e->stream);
   delete e;
 }
@@ -338,7 +348,7 @@ int pal_corr_metrics(pal_handle h, const double* corr, int n, pal_pair_record* r
   PAL_TRY(e->check(hipMemcpyAsync(dc, corr, size_t(n) * sizeof(double), hipMemcpyHostToDevice, e->stream), "corr upload"));
   pal_phat_params p{};
   p.fs = 1; p.threshold_method = -1; p.peak_distance = 1; p.num_peaks = 1; p.max_expected_delay = NAN;
-  PAL_TRY(e->peaks(static_cast<const double*>(dc), size_t(n), 1, n, 1, p, static_cast<pal_pair_record*>(dt), nullptr));
+  PAL_TRY(e->peaks(static_cast<const double*>(dc), size_t(n), 1, n, 1, p, static_cast<pal_pair_record*>(dt), nullptr, e->stream));
   PAL_TRY(e->check(hipMemcpyAsync(rec, dt, sizeof(pal_pair_record), hipMemcpyDeviceToHost, e->stream), "record download"));
   return pal_synchronize(h);
 }

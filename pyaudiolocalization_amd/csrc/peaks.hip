@@ -1,8 +1,18 @@
-// peaks.hip - peak selection and correlation metrics for one PHAT row per workgroup (gfx950).
+// peaks.hip - peak selection and correlation metrics, one PHAT row per 512-lane workgroup (gfx950).
 //
 // Replaces utils.py:140-181 (threshold, scipy.signal.find_peaks(height, distance), the whole
 // fallback chain, window filter, top-num_peaks), utils.py:228-250 (compute_snr /
 // compute_peak_to_peak_ratio inputs) and np.max(corr) of main.py:223.
+//
+// The row (n doubles, 0.7 MB at 44.1 kHz x 1 s) is streamed ONCE with 16-byte loads, four in flight
+// per lane: max / first argmax, min, shifted sums for the SNR and the 'adaptive' threshold, the
+// highest local maximum, and - for the exact median of |corr| - the values that fall between two
+// pivots taken from an 8192-point block sample are compacted into LDS while everything below the
+// lower pivot is only counted.  The median is then an exact rank search inside LDS; if the pivots
+// missed (they bracket the median with >4 sigma of the sample's rank error) or LDS overflows, a
+// radix select over the IEEE-754 bit pattern re-reads the row (11-bit digits, LDS histograms).
+// The tiles of the pass are branch-free (guarded loads serialise on s_waitcnt); lane 0 / lane 63 of
+// every wavefront leave their outer element's peak test to a short edge pass.
 //
 // scipy's find_peaks is evaluated lazily and exactly instead of materialising peak lists:
 //   - a sample m is a peak iff it is the floor-midpoint of a plateau whose two outer neighbours
@@ -11,9 +21,7 @@
 //     then position) lies closer than `distance`; that recursion is resolved depth first from the
 //     candidate, with a memo, because chains of rising peaks are short   (_select_by_peak_distance)
 //   - candidates are visited in descending priority inside the lag window until num_peaks are kept.
-// The exact median of |corr| is a radix select over the IEEE-754 bit pattern (11-bit digits, LDS
-// histogram, then an in-LDS rank search once the surviving bin holds <= 2048 values).
-// Reductions: wavefront (64-lane) shuffles, then one LDS hop across the 4 wavefronts.
+// Reductions: wavefront (64-lane) shuffles, then one LDS hop across the 8 wavefronts.
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -25,26 +33,33 @@ namespace pal {
 
 namespace {
 
-constexpr int kCap = 2048;      // in-LDS rank-search capacity
-constexpr int kMemo = 1024;     // resolved peaks remembered per selection
-constexpr int kStack = 64;      // depth of the suppression recursion
+constexpr int kT = 512;           // lanes per row (1024 would cap the kernel at 128 VGPRs and spill)
+constexpr int kNW = kT / 64;      // wavefronts per row
+constexpr int kList = 16384;      // LDS capacity of the pivot bracket (doubles, 128 KiB)
+constexpr int kSample = 8192;     // strided sample that places the pivots
+constexpr int kBins = 2048;       // histogram bins (sample pivots, list search, radix digits)
+constexpr int kSmall = 1024;      // exact rank search capacity
+constexpr int kMemo = 1024;       // resolved peaks remembered per selection
+constexpr int kStack = 64;        // depth of the suppression recursion
+constexpr int kUnroll = 4;        // 16-byte loads in flight per lane
 
 struct PeakArgs {
   const double* corr;
   size_t stride;
   int n, n2;
   double fs, mult, med;   // med: NaN = no window
-  int method, dist, num_peaks, snr_w;
+  int method, dist, num_peaks, snr_w;   // method: 0 median, 1 adaptive, < 0 metrics only
 };
 
 struct Shared {
-  unsigned hist[2048];
-  double list[kCap];
-  double red_d[8];
-  int red_i[8];
-  unsigned scan[kLanes];
-  int count;
-  // selection state
+  double list[kList];
+  unsigned hist[kBins];
+  double small[kSmall];
+  double red_d[kNW];
+  int red_i[kNW];
+  long long red_l[kNW];
+  unsigned wave_tot[kNW];
+  int count, count2;
   int memo_pos[kMemo];
   int memo_kept[kMemo];
   int memo_n;
@@ -60,10 +75,60 @@ __device__ __forceinline__ bool higher(double h1, int m1, double h2, int m2) {  
   return h1 > h2 || (h1 == h2 && m1 > m2);
 }
 
-// ---- block reductions (result valid in every lane): reduce.h over this kernel's LDS slots ----
-__device__ double block_sum(double v, Shared& s, int tid) { return pal::block_sum(v, s.red_d, tid); }
-template <int MODE> __device__ void block_arg(double& v, int& i, Shared& s, int tid) {
-  pal::block_arg<MODE>(v, i, s.red_d, s.red_i, tid);
+__device__ double bsum(double v, Shared& s, int tid) { return block_sum<kNW>(v, s.red_d, tid); }
+__device__ long long bsum_ll(long long v, Shared& s, int tid) { return block_sum_ll<kNW>(v, s.red_l, tid); }
+template <int MODE> __device__ void barg(double& v, int& i, Shared& s, int tid) {
+  block_arg<MODE, kNW>(v, i, s.red_d, s.red_i, tid);
+}
+
+// exclusive prefix sum over the workgroup (one value per lane)
+__device__ unsigned block_excl_scan(unsigned v, Shared& s, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  unsigned inc = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) s.wave_tot[wave] = inc;
+  __syncthreads();
+  unsigned before = 0;
+  for (int k = 0; k < wave; ++k) before += s.wave_tot[k];
+  return before + inc - v;
+}
+
+// bin of s.hist that holds 0-based rank `rank` (2 bins per lane); rank inside the bin and its population
+__device__ void find_bin(Shared& s, int tid, unsigned rank, unsigned& bin, unsigned& inner, unsigned& pop) {
+  constexpr int kPer = kBins / kT;                  // consecutive bins owned by one lane
+  unsigned h[kPer], own = 0;
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) { h[q] = s.hist[kPer * tid + q]; own += h[q]; }
+  unsigned ex = block_excl_scan(own, s, tid);
+  if (tid == 0) s.bc_i[0] = -1;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    if (rank >= ex && rank < ex + h[q]) { s.bc_i[0] = kPer * tid + q; s.bc_i[1] = int(rank - ex); s.bc_i[2] = int(h[q]); }
+    ex += h[q];
+  }
+  __syncthreads();
+  if (s.bc_i[0] < 0) { bin = kBins - 1; inner = 0; pop = 0; }   // rank beyond the histogram's total
+  else { bin = unsigned(s.bc_i[0]); inner = unsigned(s.bc_i[1]); pop = unsigned(s.bc_i[2]); }
+  __syncthreads();
+}
+
+// wavefront-aggregated append to an LDS list (one LDS atomic per wavefront)
+__device__ __forceinline__ void append(bool pred, double v, double* list, int* counter, int cap, int lane) {
+  const unsigned long long mask = __ballot(pred);
+  if (mask == 0) return;
+  const int leader = __ffsll((long long)mask) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+  base = __shfl(base, leader, 64);
+  if (pred) {
+    const int at = base + __popcll(mask & ((1ull << lane) - 1ull));
+    if (at < cap) list[at] = v;
+  }
 }
 
 // ---- scipy _local_maxima_1d, evaluated for one sample ----
@@ -80,127 +145,105 @@ __device__ bool peak_mid(const double* c, int n, int m, double& h) {
   return true;
 }
 
-// ---- radix select digits over the 63 magnitude bits ----
-__device__ __forceinline__ int digit_shift(int level) { return level < 5 ? 52 - 11 * level : 0; }
-__device__ __forceinline__ unsigned digit_mask(int level) { return level < 5 ? 0x7FFu : 0xFFu; }
-__device__ __forceinline__ unsigned long long mag_key(double x) {
-  return (unsigned long long)__double_as_longlong(fabs(x));
-}
-__device__ __forceinline__ bool key_matches(unsigned long long key, int level, unsigned long long prefix) {
-  return level == 0 || (key >> digit_shift(level - 1)) == prefix;
-}
-
-// find the histogram bin that holds 0-based rank `rank`; returns bin, rank inside it and its population
-__device__ void find_bin(Shared& s, int tid, unsigned rank, unsigned& bin, unsigned& inner, unsigned& pop) {
-  // 2048 bins = 256 lanes x 8 consecutive bins
-  unsigned local = 0;
-  for (int k = 0; k < 8; ++k) local += s.hist[tid * 8 + k];
-  s.scan[tid] = local;
+// ---- exact rank inside an LDS list whose values lie in [lo, hi] ----
+// linear bins spread the bracket over the histogram; the winning bin (a handful of values) is ranked by counting.
+// returns false when that bin is too crowded for the exact search (caller falls back to the radix select)
+__device__ bool list_select(Shared& s, int tid, int cnt, unsigned rank, double lo, double hi, double& out) {
+  for (int k = tid; k < kBins; k += kT) s.hist[k] = 0;
+  if (tid == 0) s.count2 = 0;
   __syncthreads();
-  if (tid == 0) {
-    unsigned acc = 0;
-    int t = 0;
-    while (t < kLanes - 1 && acc + s.scan[t] <= rank) { acc += s.scan[t]; ++t; }
-    int b = t * 8;
-    while (b < t * 8 + 7 && acc + s.hist[b] <= rank) { acc += s.hist[b]; ++b; }
-    s.bc_i[0] = b;
-    s.bc_i[1] = int(rank - acc);
-    s.bc_i[2] = int(s.hist[b]);
+  const double span = hi - lo;
+  const double inv = (span > 0 && isfinite(span)) ? double(kBins - 1) / span : 0.0;
+  for (int e = tid; e < cnt; e += kT) {
+    int b = int((s.list[e] - lo) * inv);
+    b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+    atomicAdd(&s.hist[b], 1u);
   }
   __syncthreads();
-  bin = unsigned(s.bc_i[0]);
-  inner = unsigned(s.bc_i[1]);
-  pop = unsigned(s.bc_i[2]);
-  __syncthreads();
-}
-
-struct Extra {       // side reductions carried by the passes over the row
-  int kind;          // 0 none, 1 sums outside [lo,hi) (+ sum (|x|-mabs)^2), 2 sum (x-mean)^2 outside [lo,hi)
-  int lo, hi;
-  double mean, mabs;
-  double out0, out1;
-};
-
-// one streaming pass over the row: optional histogram of digit `level` among keys matching `prefix`,
-// optional compaction of the matching magnitudes into s.list, optional side reductions
-__device__ void stream_pass(const double* c, int n, int tid, Shared& s, bool do_hist, bool do_compact, int level,
-                            unsigned long long prefix, Extra& ex) {
-  if (do_hist) for (int k = tid; k < 2048; k += kLanes) s.hist[k] = 0;
-  if (do_compact && tid == 0) s.count = 0;
-  __syncthreads();
-  double a0 = 0, a1 = 0;
-  const int sh = digit_shift(level);
-  const unsigned mk_ = digit_mask(level);
-  for (int i = tid; i < n; i += kLanes) {
-    const double x = c[i];
-    if (do_hist || do_compact) {
-      const unsigned long long key = mag_key(x);
-      if (key_matches(key, level, prefix)) {
-        if (do_hist) atomicAdd(&s.hist[unsigned(key >> sh) & mk_], 1u);
-        if (do_compact) {
-          const int p = atomicAdd(&s.count, 1);
-          if (p < kCap) s.list[p] = fabs(x);
-        }
-      }
+  unsigned bin, inner, pop;
+  find_bin(s, tid, rank, bin, inner, pop);
+  if (pop == 0 || pop > unsigned(kSmall)) return false;
+  for (int e0 = 0; e0 < cnt; e0 += kT) {
+    const int e = e0 + tid;
+    bool hit = false;
+    double v = 0;
+    if (e < cnt) {
+      v = s.list[e];
+      int b = int((v - lo) * inv);
+      b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+      hit = unsigned(b) == bin;
     }
-    if (ex.kind == 1) {
-      if (i < ex.lo || i >= ex.hi) a0 += x;
-      const double d = fabs(x) - ex.mabs;
-      a1 += d * d;
-    } else if (ex.kind == 2) {
-      if (i < ex.lo || i >= ex.hi) { const double d = x - ex.mean; a0 += d * d; }
-    }
-  }
-  if (ex.kind != 0) {
-    ex.out0 = block_sum(a0, s, tid);
-    ex.out1 = block_sum(a1, s, tid);
+    append(hit, v, s.small, &s.count2, kSmall, tid & 63);
   }
   __syncthreads();
-}
-
-// value of 0-based rank `inner` among the s.count magnitudes compacted in s.list
-__device__ double list_rank(Shared& s, int tid, unsigned inner) {
-  const int cnt = s.count;
-  if (tid == 0) s.bc_d[0] = 0;
-  __syncthreads();
-  for (int e = tid; e < cnt; e += kLanes) {
-    const double v = s.list[e];
+  const int m = s.count2;
+  for (int e = tid; e < m; e += kT) {
+    const double v = s.small[e];
     unsigned below = 0;
-    for (int j = 0; j < cnt; ++j) {
-      const double u = s.list[j];
+    for (int j = 0; j < m; ++j) {
+      const double u = s.small[j];
       below += (u < v) || (u == v && j < e);
     }
     if (below == inner) s.bc_d[0] = v;
   }
   __syncthreads();
-  const double r = s.bc_d[0];
+  out = s.bc_d[0];
   __syncthreads();
-  return r;
+  return true;
 }
 
-// radix select of |corr| at 0-based `rank`.  `have_level0` says s.hist already holds the digit-0
-// histogram.  Side reductions queued in exq[] ride along with the passes; any left over are run after.
-__device__ double select_rank(const double* c, int n, int tid, Shared& s, unsigned rank, bool have_level0, Extra* exq,
-                              int& ex_next, int ex_count) {
-  Extra none{0, 0, 0, 0, 0, 0, 0};
+// ---- fallback: radix select over the 63 magnitude bits, re-reading the row ----
+__device__ __forceinline__ int digit_shift(int level) { return level < 5 ? 52 - 11 * level : 0; }
+__device__ __forceinline__ unsigned digit_mask(int level) { return level < 5 ? 0x7FFu : 0xFFu; }
+__device__ __forceinline__ unsigned long long mag_key(double x) { return (unsigned long long)__double_as_longlong(fabs(x)); }
+
+__device__ double radix_select(const double* c, int n, int tid, Shared& s, unsigned rank) {
   unsigned long long prefix = 0;
-  int level = 0;
-  if (!have_level0) stream_pass(c, n, tid, s, true, false, 0, 0, none);
   unsigned inner = rank, bin, pop;
-  for (;;) {
+  for (int level = 0; level < 6; ++level) {
+    for (int k = tid; k < kBins; k += kT) s.hist[k] = 0;
+    __syncthreads();
+    const int sh = digit_shift(level);
+    const unsigned mk_ = digit_mask(level);
+    for (int i = tid; i < n; i += kT) {
+      const unsigned long long key = mag_key(c[i]);
+      if (level == 0 || (key >> digit_shift(level - 1)) == prefix) atomicAdd(&s.hist[unsigned(key >> sh) & mk_], 1u);
+    }
+    __syncthreads();
     find_bin(s, tid, inner, bin, inner, pop);
     prefix = (prefix << (level < 5 ? 11 : 8)) | bin;
-    ++level;
-    if (pop <= unsigned(kCap) || level == 6) break;
-    Extra& ex = ex_next < ex_count ? exq[ex_next] : none;
-    stream_pass(c, n, tid, s, true, false, level, prefix, ex);
-    if (&ex != &none) ++ex_next;
+    if (pop <= unsigned(kSmall) && level < 5) {
+      // few survivors: rank them exactly
+      if (tid == 0) s.count2 = 0;
+      __syncthreads();
+      for (int i0 = 0; i0 < n; i0 += kT) {
+        const int i = i0 + tid;
+        bool hit = false;
+        double v = 0;
+        if (i < n) {
+          v = fabs(c[i]);
+          hit = (mag_key(v) >> sh) == prefix;
+        }
+        append(hit, v, s.small, &s.count2, kSmall, tid & 63);
+      }
+      __syncthreads();
+      const int m = s.count2;
+      for (int e = tid; e < m; e += kT) {
+        const double v = s.small[e];
+        unsigned below = 0;
+        for (int j = 0; j < m; ++j) {
+          const double u = s.small[j];
+          below += (u < v) || (u == v && j < e);
+        }
+        if (below == inner) s.bc_d[0] = v;
+      }
+      __syncthreads();
+      const double r = s.bc_d[0];
+      __syncthreads();
+      return r;
+    }
   }
-  if (level == 6) return __longlong_as_double((long long)prefix);   // every magnitude bit fixed
-  Extra& ex = ex_next < ex_count ? exq[ex_next] : none;
-  stream_pass(c, n, tid, s, false, true, level, prefix, ex);
-  if (&ex != &none) ++ex_next;
-  return list_rank(s, tid, inner);
+  return __longlong_as_double((long long)prefix);   // every magnitude bit fixed: all survivors are equal
 }
 
 // ---- greedy distance suppression, resolved from one candidate ----
@@ -210,7 +253,7 @@ __device__ int memo_find(const Shared& s, int pos) {
   return -1;
 }
 
-// returns 1 kept, 0 suppressed, -1 overflow; block-uniform control flow
+// returns 1 kept, 0 suppressed, -1 overflow; workgroup-uniform control flow
 __device__ int resolve(const double* c, int n, int dist, int tid, Shared& s, int pos0, double h0) {
   if (tid == 0) { s.stack_n = 1; s.stack_pos[0] = pos0; s.stack_h[0] = h0; s.flag = 0; }
   __syncthreads();
@@ -225,11 +268,10 @@ __device__ int resolve(const double* c, int n, int dist, int tid, Shared& s, int
       __syncthreads();
       continue;
     }
-    // neighbours closer than dist with higher priority
-    int any_kept = 0;
+    int any_kept = 0;                                 // neighbours closer than dist with higher priority
     double bh = 0;
     int bm = -1;
-    for (int o = tid - (dist - 1); o <= dist - 1; o += kLanes) {
+    for (int o = tid - (dist - 1); o <= dist - 1; o += kT) {
       if (o == 0) continue;
       const int m = p + o;
       double hm;
@@ -240,7 +282,7 @@ __device__ int resolve(const double* c, int n, int dist, int tid, Shared& s, int
       }
     }
     any_kept = __syncthreads_or(any_kept);
-    block_arg<2>(bh, bm, s, tid);
+    barg<2>(bh, bm, s, tid);
     if (tid == 0) {
       if (any_kept || bm < 0) {
         if (s.memo_n < kMemo) {
@@ -273,12 +315,12 @@ __device__ __forceinline__ bool in_window(int m, int n2, double fs, double med) 
 }
 
 // highest-priority peak with height >= thr inside [wlo, whi] (exact window test when windowed) and
-// priority below (bh, bm); returns false when none
+// priority below (bound_h, bound_m); returns false when none
 __device__ bool next_candidate(const PeakArgs& a, const double* c, int tid, Shared& s, double thr, bool windowed, int wlo,
                                int whi, double bound_h, int bound_m, double& ch, int& cm) {
   double bh = 0;
   int bm = -1;
-  for (int m = wlo + tid; m <= whi; m += kLanes) {
+  for (int m = wlo + tid; m <= whi; m += kT) {
     double hm;
     if (!peak_mid(c, a.n, m, hm)) continue;
     if (!(hm >= thr)) continue;
@@ -286,7 +328,7 @@ __device__ bool next_candidate(const PeakArgs& a, const double* c, int tid, Shar
     if (!higher(bound_h, bound_m, hm, m)) continue;
     if (bm < 0 || higher(hm, m, bh, bm)) { bh = hm; bm = m; }
   }
-  block_arg<2>(bh, bm, s, tid);
+  barg<2>(bh, bm, s, tid);
   ch = bh;
   cm = bm;
   return bm >= 0;
@@ -318,69 +360,222 @@ __device__ int select_peaks(const PeakArgs& a, const double* c, int tid, Shared&
   return count;
 }
 
-__global__ __launch_bounds__(256) void k_peaks(PeakArgs a, pal_pair_record* table, int32_t* ksel_multi, int* status) {
+struct Stream {            // per-lane accumulators of the single pass over the row
+  double vmax, vmin, hb;
+  int imax, imin, mb;
+  double s1, s2, a1, a2;   // sums of (x-K0), (x-K0)^2, (|x|-Ka), (|x|-Ka)^2
+  long long below;
+};
+
+__device__ __forceinline__ void visit(Stream& t, double x, int i, double k0, double ka) {
+  if (t.imax < 0 || x > t.vmax) { t.vmax = x; t.imax = i; }
+  if (t.imin < 0 || x < t.vmin) { t.vmin = x; t.imin = i; }
+  const double d = x - k0, e = fabs(x) - ka;
+  t.s1 += d;
+  t.s2 += d * d;
+  t.a1 += e;
+  t.a2 += e * e;
+}
+
+// x at index i with neighbours l (i-1) and r (i+1): record it when it is a local maximum (plateaus: slow path)
+__device__ __forceinline__ void peak_test(Stream& t, const double* c, int n, int i, double l, double x, double r) {
+  if (i < 1 || i > n - 2 || !(l < x)) return;
+  int m = i;
+  if (r == x) {                                    // plateau that starts here: find its right edge in memory
+    int q = i + 1;
+    while (q < n - 1 && c[q] == x) ++q;
+    if (!(c[q] < x)) return;
+    m = (i + q - 1) / 2;
+  } else if (!(r < x)) {
+    return;
+  }
+  if (t.mb < 0 || higher(x, m, t.hb, t.mb)) { t.hb = x; t.mb = m; }
+}
+
+__global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table, int32_t* ksel_multi, int* status) {
   __shared__ Shared s;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int row = blockIdx.x;
   const double* c = a.corr + size_t(row) * a.stride;
   const int n = a.n;
-
-  // ---- pass A: max/argmax, min, sum|x|, exponent histogram, highest local maximum ----
-  for (int k = tid; k < 2048; k += kLanes) s.hist[k] = 0;
-  __syncthreads();
-  double vmax = -INFINITY, vmin = INFINITY, sabs = 0, hb = 0;
-  int imax = -1, imin = -1, mb = -1;
   const bool want_median = a.method == 0;
-  for (int i = tid; i < n; i += kLanes) {
-    const double x = c[i];
-    if (imax < 0 || x > vmax) { vmax = x; imax = i; }
-    if (imin < 0 || x < vmin) { vmin = x; imin = i; }
-    sabs += fabs(x);
-    if (want_median) atomicAdd(&s.hist[unsigned(mag_key(x) >> 52) & 0x7FFu], 1u);
-    if (i >= 1 && i <= n - 2 && c[i - 1] < x) {          // rising edge: owns the plateau that starts here
-      int r = i + 1;
-      while (r < n - 1 && c[r] == x) ++r;
-      if (c[r] < x) {
-        const int m = (i + r - 1) / 2;
-        if (mb < 0 || higher(x, m, hb, mb)) { hb = x; mb = m; }
+
+  // ---- block sample (16 coalesced runs of kT samples spread over the row): shifts for the one-pass
+  //      variances and the pivots that bracket the median ----
+  constexpr int kRuns = kSample / kT;
+  const int ns = n < kSample ? n : kSample;
+  double sv[kRuns];
+  double ssum = 0, sabs = 0;
+#pragma unroll
+  for (int q = 0; q < kRuns; ++q) {
+    const int si = tid + q * kT;
+    const size_t at = n <= kSample ? size_t(si) : size_t((long long)q * (n - kT) / (kRuns - 1)) + tid;
+    sv[q] = si < ns ? c[at] : 0.0;
+    ssum += sv[q];
+    sabs += fabs(sv[q]);
+  }
+  const double k0 = bsum(ssum, s, tid) / double(ns);          // ~ mean(x)
+  const double ka = bsum(sabs, s, tid) / double(ns);          // ~ mean(|x|)
+  const unsigned r1 = unsigned((n - 1) / 2), r2 = unsigned(n / 2);   // ranks of the median's one or two order statistics
+  double lo = 0, hi = INFINITY;
+  if (want_median) {
+    for (int k = tid; k < kBins; k += kT) s.hist[k] = 0;
+    __syncthreads();
+    const double top = ka > 0 ? 4.0 * ka : 1.0;               // median <= 2 mean for non-negative data
+    const double inv = double(kBins - 1) / top;
+#pragma unroll
+    for (int q = 0; q < kSample / kT; ++q) {
+      if (tid + q * kT < ns) {
+        int b = int(fabs(sv[q]) * inv);
+        atomicAdd(&s.hist[b < kBins - 1 ? b : kBins - 1], 1u);
       }
     }
+    __syncthreads();
+    const int margin = int(2.0 * sqrt(double(ns))) + 8;      // 4 sigma of the sample median's rank
+    const long long c1 = (long long)r1 * ns / n, c2 = (long long)r2 * ns / n;
+    const unsigned slo = unsigned(c1 - margin > 0 ? c1 - margin : 0);
+    const unsigned shi = unsigned(c2 + margin < ns - 1 ? c2 + margin : ns - 1);
+    unsigned b_lo, b_hi, t0, t1;
+    find_bin(s, tid, slo, b_lo, t0, t1);
+    find_bin(s, tid, shi, b_hi, t0, t1);
+    lo = double(b_lo) / inv;
+    hi = b_hi >= unsigned(kBins - 1) ? INFINITY : double(b_hi + 1) / inv;
+    if (slo == 0) lo = 0;
+    if (shi == unsigned(ns - 1)) hi = INFINITY;
   }
-  block_arg<0>(vmax, imax, s, tid);
-  block_arg<1>(vmin, imin, s, tid);
-  block_arg<2>(hb, mb, s, tid);
-  sabs = block_sum(sabs, s, tid);
-  const double mean_abs = sabs / double(n);               // np.mean(np.abs(corr)) (utils.py:155)
+  if (tid == 0) s.count = 0;
+  __syncthreads();
 
-  // ---- SNR window (utils.py:244-247) and the side reductions that ride on later passes ----
-  const int lo = imax - a.snr_w > 0 ? imax - a.snr_w : 0;
-  const int hi = imax + a.snr_w < n ? imax + a.snr_w : n;
-  const int noise_n = lo + (n - hi);
-  Extra exq[2];
-  exq[0] = Extra{1, lo, hi, 0.0, mean_abs, 0, 0};
-  exq[1] = Extra{2, lo, hi, 0.0, 0.0, 0, 0};
-  int ex_next = 0;
+  // ---- the single pass: branch-free tiles of kUnroll 16-byte loads per lane, then a short guarded tail ----
+  Stream t;
+  t.vmax = t.vmin = t.hb = 0;
+  t.imax = t.imin = t.mb = -1;
+  t.s1 = t.s2 = t.a1 = t.a2 = 0;
+  t.below = 0;
+  const bool aligned = (reinterpret_cast<size_t>(c) & 15) == 0;
+  const int npair = (n + 1) / 2;
+  constexpr int kTile = kT * kUnroll;                          // element pairs per tile
+  const int full = ((n / 2) / kTile) * kTile;                  // pairs covered by tiles in which every lane is valid
+  // Element e = 2p (+1) of pair p; lane = p % 64.  Neighbours come from the adjacent lanes; the first element
+  // of lane 0 and the second of lane 63 (e % 128 == 0 / 127) are peak-tested by the edge pass below instead.
+  auto consume = [&](double xa, double xb, int e0, bool va, bool vb) {
+    const double left = __shfl_up(xb, 1, 64);
+    const double right = __shfl_down(xa, 1, 64);
+    if (va) {
+      visit(t, xa, e0, k0, ka);
+      if (lane != 0) peak_test(t, c, n, e0, left, xa, xb);
+    }
+    if (vb) {
+      visit(t, xb, e0 + 1, k0, ka);
+      if (lane != 63) peak_test(t, c, n, e0 + 1, xa, xb, right);
+    }
+    if (want_median) {
+      const double ma = fabs(xa), mb_ = fabs(xb);
+      t.below += (va && ma < lo) + (vb && mb_ < lo);
+      append(va && ma >= lo && ma <= hi, ma, s.list, &s.count, kList, lane);
+      append(vb && mb_ >= lo && mb_ <= hi, mb_, s.list, &s.count, kList, lane);
+    }
+  };
+  if (aligned) {
+    for (int base = 0; base < full; base += kTile) {
+      double2 v[kUnroll];
+#pragma unroll
+      for (int k = 0; k < kUnroll; ++k) v[k] = *reinterpret_cast<const double2*>(c + 2 * (base + k * kT + tid));
+#pragma unroll
+      for (int k = 0; k < kUnroll; ++k) consume(v[k].x, v[k].y, 2 * (base + k * kT + tid), true, true);
+    }
+  } else {
+    for (int base = 0; base < full; base += kTile) {
+      double xa[kUnroll], xb[kUnroll];
+#pragma unroll
+      for (int k = 0; k < kUnroll; ++k) {
+        xa[k] = c[2 * (base + k * kT + tid)];
+        xb[k] = c[2 * (base + k * kT + tid) + 1];
+      }
+#pragma unroll
+      for (int k = 0; k < kUnroll; ++k) consume(xa[k], xb[k], 2 * (base + k * kT + tid), true, true);
+    }
+  }
+  for (int p0 = full; p0 < npair; p0 += kT) {                  // tail: fewer than one tile of pairs
+    const int e0 = 2 * (p0 + tid);
+    const bool va = e0 < n, vb = e0 + 1 < n;
+    const double xa = va ? c[e0] : 0.0, xb = vb ? c[e0 + 1] : 0.0;
+    consume(xa, xb, e0, va, vb);
+  }
+  for (int j = tid; 64 * j < n; j += kT) {                     // edge pass: e = 128 q and e = 128 q + 127
+    const int e = (j >> 1) * 128 + ((j & 1) ? 127 : 0);
+    if (e >= 1 && e <= n - 2) peak_test(t, c, n, e, c[e - 1], c[e], c[e + 1]);
+  }
+  double vmax = t.vmax, vmin = t.vmin, hb = t.hb;
+  int imax = t.imax, imin = t.imin, mb = t.mb;
+  barg<0>(vmax, imax, s, tid);
+  barg<1>(vmin, imin, s, tid);
+  barg<2>(hb, mb, s, tid);
+  const double s1 = bsum(t.s1, s, tid), s2 = bsum(t.s2, s, tid);
+  const double a1 = bsum(t.a1, s, tid), a2 = bsum(t.a2, s, tid);
+  const double mean_abs = ka + a1 / double(n);                 // np.mean(np.abs(corr)) (utils.py:155)
+  if (imax < 0) imax = 0;                                      // all-NaN row
+
+  // ---- SNR (utils.py:238-250): totals minus the window around the maximum ----
+  const int wlo_s = imax - a.snr_w > 0 ? imax - a.snr_w : 0;
+  const int whi_s = imax + a.snr_w < n ? imax + a.snr_w : n;
+  double w1 = 0, w2 = 0;
+  for (int i = wlo_s + tid; i < whi_s; i += kT) {
+    const double d = c[i] - k0;
+    w1 += d;
+    w2 += d * d;
+  }
+  w1 = bsum(w1, s, tid);
+  w2 = bsum(w2, s, tid);
+  const double nn = double(n - (whi_s - wlo_s));
+  double o1 = s1 - w1, o2 = s2 - w2;
+  if (!(o2 >= 0.25 * s2)) {
+    // the window holds most of the row's energy (strongly correlated signals: a near-delta sequence), so
+    // "total minus window" would cancel: sum the noise region itself in one more pass
+    // (two passes like np.std: the sample mean k0 may sit 1e3 noise sigmas away when it caught the peak)
+    double q1 = 0, q2 = 0;
+    for (int i = tid; i < n; i += kT)
+      if (i < wlo_s || i >= whi_s) q1 += c[i];
+    const double mu = bsum(q1, s, tid) / nn;
+    for (int i = tid; i < n; i += kT)
+      if (i < wlo_s || i >= whi_s) { const double d = c[i] - mu; q2 += d * d; }
+    o1 = 0;
+    o2 = bsum(q2, s, tid);
+  }
+  double var = (o2 - o1 * o1 / nn) / nn;
+  if (var < 0) var = 0;
+  const double noise = sqrt(var);
+  const double snr = noise == 0.0 ? INFINITY : vmax / noise;
+
+  if (a.method < 0) {                                          // metrics only (pal_corr_metrics)
+    if (tid == 0) {
+      pal_pair_record r;
+      r.k_sel = imax; r.branch = 0; r.k_argmax = imax; r.n_sel = 0;
+      r.cmax = vmax; r.cmin = vmin; r.snr = snr; r.sel_height = vmax;
+      table[row] = r;
+    }
+    return;
+  }
+
+  // ---- primary threshold (utils.py:144-149) ----
   double thr1;
   if (want_median) {
-    double med;
-    if (n & 1) {
-      med = select_rank(c, n, tid, s, unsigned(n / 2), true, exq, ex_next, 1);
-    } else {
-      const double m0 = select_rank(c, n, tid, s, unsigned(n / 2 - 1), true, exq, ex_next, 1);
-      const double m1 = select_rank(c, n, tid, s, unsigned(n / 2), false, exq, ex_next, 1);
-      med = (m0 + m1) * 0.5;                              // np.median of an even count
+    const long long below = bsum_ll(t.below, s, tid);
+    const int cnt = s.count;
+    double m0 = 0, m1 = 0;
+    bool ok = cnt <= kList && (long long)r1 >= below && (long long)r2 < below + cnt;
+    if (ok) ok = list_select(s, tid, cnt, unsigned(r1 - below), lo, hi, m0);
+    if (ok) { m1 = m0; if (r2 != r1) ok = list_select(s, tid, cnt, unsigned(r2 - below), lo, hi, m1); }
+    if (!ok) {                                                 // pivots missed or LDS overflow: exact radix select
+      m0 = radix_select(c, n, tid, s, r1);
+      m1 = r2 != r1 ? radix_select(c, n, tid, s, r2) : m0;
     }
-    if (ex_next < 1) { stream_pass(c, n, tid, s, false, false, 0, 0, exq[0]); ex_next = 1; }
-    thr1 = a.mult * med;
+    thr1 = a.mult * (r2 != r1 ? (m0 + m1) * 0.5 : m0);         // np.median
   } else {
-    stream_pass(c, n, tid, s, false, false, 0, 0, exq[0]);
-    ex_next = 1;
-    thr1 = a.mult * (mean_abs + sqrt(exq[0].out1 / double(n)));   // mean + std of |corr| (utils.py:147)
+    double va = (a2 - a1 * a1 / double(n)) / double(n);
+    if (va < 0) va = 0;
+    thr1 = a.mult * (mean_abs + sqrt(va));                     // mean + std of |corr| (utils.py:147)
   }
-  exq[1].mean = exq[0].out0 / double(noise_n);
-  stream_pass(c, n, tid, s, false, false, 0, 0, exq[1]);
-  const double noise = sqrt(exq[1].out0 / double(noise_n));
-  const double snr = noise == 0.0 ? INFINITY : vmax / noise;
 
   // ---- fallback chain (utils.py:152-179) ----
   int branch = 0;
@@ -434,37 +629,6 @@ __global__ __launch_bounds__(256) void k_peaks(PeakArgs a, pal_pair_record* tabl
   }
 }
 
-// metrics only (max, min, argmax, snr) for rows that are not PHAT sequences
-__global__ __launch_bounds__(256) void k_metrics(PeakArgs a, pal_pair_record* table) {
-  __shared__ Shared s;
-  const int tid = threadIdx.x;
-  const double* c = a.corr + size_t(blockIdx.x) * a.stride;
-  const int n = a.n;
-  double vmax = -INFINITY, vmin = INFINITY;
-  int imax = -1, imin = -1;
-  for (int i = tid; i < n; i += kLanes) {
-    const double x = c[i];
-    if (imax < 0 || x > vmax) { vmax = x; imax = i; }
-    if (imin < 0 || x < vmin) { vmin = x; imin = i; }
-  }
-  block_arg<0>(vmax, imax, s, tid);
-  block_arg<1>(vmin, imin, s, tid);
-  const int lo = imax - a.snr_w > 0 ? imax - a.snr_w : 0;
-  const int hi = imax + a.snr_w < n ? imax + a.snr_w : n;
-  const int noise_n = lo + (n - hi);
-  Extra e1{1, lo, hi, 0.0, 0.0, 0, 0};
-  stream_pass(c, n, tid, s, false, false, 0, 0, e1);
-  Extra e2{2, lo, hi, e1.out0 / double(noise_n), 0.0, 0, 0};
-  stream_pass(c, n, tid, s, false, false, 0, 0, e2);
-  const double noise = sqrt(e2.out0 / double(noise_n));
-  if (tid == 0) {
-    pal_pair_record r;
-    r.k_sel = imax; r.branch = 0; r.k_argmax = imax; r.n_sel = 0;
-    r.cmax = vmax; r.cmin = vmin; r.snr = noise == 0.0 ? INFINITY : vmax / noise; r.sel_height = vmax;
-    table[blockIdx.x] = r;
-  }
-}
-
 }  // namespace
 
 static int* g_status_dev(Engine* e) {
@@ -474,10 +638,13 @@ static int* g_status_dev(Engine* e) {
 }
 
 int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, const pal_phat_params& prm,
-                  pal_pair_record* table, int32_t* ksel_multi) {
+                  pal_pair_record* table, int32_t* ksel_multi, hipStream_t on) {
   if (rows <= 0) return PAL_OK;
-  if (prm.num_peaks < 1 || prm.num_peaks > PAL_MAX_PEAKS) return fail(PAL_ERR_INVALID, "num_peaks %d outside 1..%d", prm.num_peaks, PAL_MAX_PEAKS);
-  if (prm.peak_distance < 1) return fail(PAL_ERR_INVALID, "`distance` must be greater or equal to 1");
+  const bool metrics_only = prm.threshold_method < 0;
+  if (!metrics_only) {
+    if (prm.num_peaks < 1 || prm.num_peaks > PAL_MAX_PEAKS) return fail(PAL_ERR_INVALID, "num_peaks %d outside 1..%d", prm.num_peaks, PAL_MAX_PEAKS);
+    if (prm.peak_distance < 1) return fail(PAL_ERR_INVALID, "`distance` must be greater or equal to 1");
+  }
   if (n < 1) return fail(PAL_ERR_INVALID, "empty correlation");
   int* status = g_status_dev(this);
   if (!status) return fail(PAL_ERR_NOMEM, "status word");
@@ -487,12 +654,8 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
   a.method = prm.threshold_method; a.dist = prm.peak_distance; a.num_peaks = prm.num_peaks;
   const int w = int(0.01 * double(n));                       // utils.py:244
   a.snr_w = w > 1 ? w : 1;
-  ProfScope ps(this, prm.threshold_method < 0 ? "k_metrics" : "k_peaks");
-  if (prm.threshold_method < 0) {
-    k_metrics<<<dim3(rows), dim3(kLanes), 0, stream>>>(a, table);
-  } else {
-    k_peaks<<<dim3(rows), dim3(kLanes), 0, stream>>>(a, table, ksel_multi, status);
-  }
+  ProfScope ps(this, metrics_only ? "k_peaks(metrics)" : "k_peaks", on);
+  k_peaks<<<dim3(rows), dim3(kT), 0, on>>>(a, table, ksel_multi, status);
   return check(hipGetLastError(), "k_peaks");
 }
 

@@ -91,23 +91,57 @@ def speed():
     from pyaudiolocalization_amd import make_params, RECORD
     from pyaudiolocalization_amd.synthetic import metric_frames
     frames = metric_frames(1, 64)
+    prm = make_params(44100, 1, "median", 1.0, 0.05)
+    ref = None
+    for overlap in (1, 0):
+        for chunk in (16, 32, 64, 128):
+            os.environ["PAL_OVERLAP"] = str(overlap)
+            e2 = Engine(0)
+            e2.set_chunk(chunk)
+            d_f = e2.alloc(frames.nbytes); e2.upload(d_f, frames)
+            d_t = e2.alloc(2016 * RECORD.itemsize)
+            e2.gcc_phat_all_pairs_dev(d_f, 1, 64, 44100, prm, d_t); e2.synchronize()
+            t = time.time()
+            for _ in range(5):
+                e2.gcc_phat_all_pairs_dev(d_f, 1, 64, 44100, prm, d_t)
+            e2.synchronize()
+            dt = (time.time() - t) / 5
+            tab = np.zeros(2016, dtype=RECORD); e2.download(tab, d_t)
+            if ref is None:
+                ref = tab.copy()
+            same = np.array_equal(tab["k_sel"], ref["k_sel"]) and np.array_equal(tab["branch"], ref["branch"])
+            print(f"  overlap={overlap} chunk={chunk:3d}: {2016 / dt:9.0f} pairs/s ({dt * 1e3:6.2f} ms per frame) table same as first: {same}", flush=True)
+            if chunk == 32:
+                e2.profile_begin()
+                for _ in range(3):
+                    e2.gcc_phat_all_pairs_dev(d_f, 1, 64, 44100, prm, d_t)
+                e2.synchronize()
+                e2.profile_end()
+                for k, v in sorted(e2.profile_entries().items(), key=lambda kv: -kv[1][0]):
+                    if v[1]:
+                        print(f"    {k:40s} {v[0]:9.3f} ms {v[1]:5d} launches {v[0] / v[1] * 1e3:9.1f} us avg")
+            e2.free(d_f); e2.free(d_t); e2.close()
+
+
+def peaksvar():
+    """Where does k_peaks spend its time?  Same frame, four parameter mixes that switch phases off."""
+    from pyaudiolocalization_amd import make_params, RECORD
+    from pyaudiolocalization_amd.synthetic import metric_frames
+    frames = metric_frames(1, 64)
     d_f = eng.alloc(frames.nbytes); eng.upload(d_f, frames)
     d_t = eng.alloc(2016 * RECORD.itemsize)
-    prm = make_params(44100, 1, "median", 1.0, 0.05)
-    eng.gcc_phat_all_pairs_dev(d_f, 1, 64, 44100, prm, d_t); eng.synchronize()
-    eng.profile_begin()
-    t = time.time()
-    for _ in range(3):
-        eng.gcc_phat_all_pairs_dev(d_f, 1, 64, 44100, prm, d_t)
-    eng.synchronize()
-    dt = time.time() - t
-    eng.profile_end()
-    print(f"  metric frame: {3 * 2016 / dt:.0f} pairs/s ({dt / 3 * 1e3:.1f} ms per frame)")
-    for k, v in sorted(eng.profile_entries().items(), key=lambda kv: -kv[1][0]):
-        if v[1]:
-            print(f"    {k:40s} {v[0]:9.3f} ms {v[1]:5d} launches {v[0] / v[1] * 1e3:9.1f} us avg")
+    for meth in ("median", "adaptive"):
+        for med in (0.05, None):
+            prm = make_params(44100, 1, meth, 1.0, med)
+            eng.gcc_phat_all_pairs_dev(d_f, 1, 64, 44100, prm, d_t); eng.synchronize()
+            eng.profile_begin()
+            for _ in range(3):
+                eng.gcc_phat_all_pairs_dev(d_f, 1, 64, 44100, prm, d_t)
+            eng.synchronize(); eng.profile_end()
+            ms, cnt = eng.profile_get("k_peaks")
+            print(f"  method={meth:8s} window={med}: k_peaks {ms / cnt * 1e3:8.1f} us per launch of 64 rows", flush=True)
 
 
-for name, fn in (("phat", phat), ("select", select), ("allpairs", allpairs), ("sim", sim), ("filters", filters), ("xcorr", xcorr), ("speed", speed)):
+for name, fn in (("peaksvar", peaksvar), ("phat", phat), ("select", select), ("allpairs", allpairs), ("sim", sim), ("filters", filters), ("xcorr", xcorr), ("speed", speed)):
     if len(sys.argv) < 2 or name in sys.argv[1:]:
         section(name, fn)
