@@ -156,23 +156,34 @@ const cd* Engine::stage_table(int ln) {
   return stage_tw[ln];
 }
 
-static void split_log2(int lm, int& l1, int& l2) {
-  l2 = lm <= 19 ? (lm - 6 < 10 ? lm - 6 : 10) : 11;
-  l1 = lm - l2;
-}
-
-int Engine::alloc_conv(Conv& c, int lm) {
+// Convolution geometry for at least `needed` points: the smaller of 2^k and 3 * 2^k (k >= 12 for the latter, so
+// that a transform is a whole number of 4096-point row tiles).
+int Engine::alloc_conv(Conv& c, size_t needed) {
+  int lm = ceil_log2(needed);
   if (lm < 12) lm = 12;
-  if (lm > 22) return fail(PAL_ERR_UNSUPPORTED, "convolution length 2^%d exceeds 2^22", lm);
-  c.lm = lm;
-  split_log2(lm, c.l1, c.l2);
+  if (lm > 22) return fail(PAL_ERR_UNSUPPORTED, "convolution of %zu points exceeds 2^22", needed);
+  c.r3 = false;
+  c.m = size_t(1) << lm;
+  c.l2 = lm <= 19 ? (lm - 6 < 10 ? lm - 6 : 10) : 11;
+  c.l1 = lm - c.l2;
+  const int k3 = lm - 2;                                   // 3 * 2^(lm-2) = 0.75 * 2^lm
+  if (allow_r3 && k3 >= 12 && (size_t(3) << k3) >= needed) {
+    int l2 = k3 - 4 < 10 ? k3 - 4 : 10;
+    int l1 = k3 - l2;
+    if (l1 > 8) { l2 = 11; l1 = k3 - l2; }
+    if (l1 >= 4 && l1 <= 8) {
+      c.r3 = true;
+      c.m = size_t(3) << k3;
+      c.l1 = l1;
+      c.l2 = l2;
+    }
+  }
   if (!stage_table(c.l1) || !stage_table(c.l2)) return fail(PAL_ERR_NOMEM, "twiddle tables");
-  const size_t M = c.M();
-  PAL_HIP(hipMalloc(&c.chat, M * sizeof(cd)));
-  PAL_HIP(hipMalloc(&c.twA, sizeof(cd) << c.l1));
+  PAL_HIP(hipMalloc(&c.chat, c.m * sizeof(cd)));
+  PAL_HIP(hipMalloc(&c.twA, sizeof(cd) * c.M1()));
   PAL_HIP(hipMalloc(&c.twB, sizeof(cd) << c.l2));
-  k_make_roots<<<dim3(((1 << c.l1) + 255) / 256), dim3(256), 0, stream>>>(c.twA, 1 << c.l1, double(1 << c.l1));
-  k_make_roots<<<dim3(((1 << c.l2) + 255) / 256), dim3(256), 0, stream>>>(c.twB, 1 << c.l2, double(M));
+  k_make_roots<<<dim3((c.M1() + 255) / 256), dim3(256), 0, stream>>>(c.twA, c.M1(), double(c.M1()));
+  k_make_roots<<<dim3(((1 << c.l2) + 255) / 256), dim3(256), 0, stream>>>(c.twB, 1 << c.l2, double(c.m));
   return check(hipGetLastError(), "k_make_roots");
 }
 
@@ -186,7 +197,7 @@ void Engine::free_conv(Conv& c) {
 int Engine::build_conv(Conv& c, const cd* w, int n, int neg_count, int pos_count, bool conj_kernel,
                        double extra_scale) {
   Engine* e = this;
-  PAL_TRY(alloc_conv(c, ceil_log2(size_t(neg_count) + size_t(pos_count) - 1)));
+  PAL_TRY(alloc_conv(c, size_t(neg_count) + size_t(pos_count) - 1));
   // chirp spectrum: column FFTs + twiddle, then forward row FFTs, scaled, in [k1][k2] order
   ChirpLoader ld{w, neg_count, pos_count, unsigned(c.M()), conj_kernel};
   PAL_TRY(launch_cols_fwd(e, c, 1, ld, c.chat));

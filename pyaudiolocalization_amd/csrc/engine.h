@@ -15,13 +15,18 @@
 
 namespace pal {
 
-// One power-of-two circular convolution of length M = M1 x M2 (four-step, both factors in LDS).
+// One circular convolution of length M = M1 x M2 (four-step, both factors in LDS).
+// M2 = 2^l2; M1 = 2^l1, or 3 * 2^l1 (r3) when the 3 * 2^k length is the smaller fit.
 struct Conv {
-  int lm = 0, l1 = 0, l2 = 0;   // log2 of M, M1 (column transforms), M2 (row transforms)
+  int l1 = 0, l2 = 0;
+  bool r3 = false;
+  size_t m = 0;                  // points per transform
   cd* chat = nullptr;            // FFT_M of the chirp kernel in [k1][k2] order, pre-scaled
   cd* twA = nullptr;             // exp(-2 pi i q / M1), q < M1
   cd* twB = nullptr;             // exp(-2 pi i r / M),  r < M2
-  size_t M() const { return size_t(1) << lm; }
+  size_t M() const { return m; }
+  int M1() const { return (r3 ? 3 : 1) << l1; }
+  int M2() const { return 1 << l2; }
 };
 
 // Exact-length-n DFT plan (Bluestein / chirp-z): forward real -> half spectrum, inverse pairs.
@@ -46,8 +51,9 @@ struct Engine {
   hipStream_t stream2 = nullptr;   // peak selection of launch group g while the passes of g+1 run on `stream`
   hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams
   bool overlap = true;
+  bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
   std::string err;
-  int chunk = 32;                               // transforms per launch group
+  int chunk = 64;                               // transforms per launch group (W = 64 x 3 MB stays in the 256 MiB Infinity Cache)
   std::map<std::tuple<int, int, int>, Plan> plans;   // (n, lin, nout) -> plan
   cd* stage_tw[12] = {};                        // stage-major twiddles per log2 N
   // growable device scratch
@@ -72,7 +78,7 @@ struct Engine {
   int scratch(int idx, size_t bytes, void** out);
   const cd* stage_table(int ln);
   int get_plan(int n, int lin, int nout, Plan** out);
-  int alloc_conv(Conv& c, int lm);      // tables + chirp-spectrum storage of a 2^lm convolution
+  int alloc_conv(Conv& c, size_t needed);   // geometry, tables and chirp-spectrum storage for >= `needed` points
   void free_conv(Conv& c);
   int build_conv(Conv& c, const cd* w, int n, int neg_count, int pos_count, bool conj_kernel, double extra_scale);
   // profiling helpers

@@ -100,25 +100,25 @@ PAL_HD constexpr int stage_tw_size(int ln) { return stage_tw_offset(ln, ln); }  
 //         memory keeps the same order, no conflicts for T >= 8).
 //   ROWS: e fastest with an XOR swizzle of the low three bits by the next three, which spreads the
 //         stride-8 writes of the first radix-8 stage over all banks.
-template <int LOG2N, bool COLS> PAL_HD int lds_addr(int t, int e) {
-  constexpr int N = 1 << LOG2N, T = kPoints / N;
-  return COLS ? e * T + t : t * N + (e ^ ((e >> 3) & 7));
+template <int LOG2N, bool COLS, int NSUB = (kPoints >> LOG2N)> PAL_HD int lds_addr(int t, int e) {
+  constexpr int N = 1 << LOG2N;
+  return COLS ? e * NSUB + t : t * N + (e ^ ((e >> 3) & 7));
 }
 
 // work item w in [0, 4096/R) -> (butterfly i, sub-transform t)
-template <int LOG2N, bool COLS, int R> PAL_HD void item_of(int w, int& i, int& t) {
-  constexpr int N = 1 << LOG2N, T = kPoints / N, NB = N / R;
-  if (COLS) { t = w % T; i = w / T; } else { i = w % NB; t = w / NB; }
+template <int LOG2N, bool COLS, int R, int NSUB = (kPoints >> LOG2N)> PAL_HD void item_of(int w, int& i, int& t) {
+  constexpr int N = 1 << LOG2N, NB = N / R;
+  if (COLS) { t = w % NSUB; i = w / NSUB; } else { i = w % NB; t = w / NB; }
 }
 
 // read the R inputs of work item w, apply the stage twiddles, run the radix-R DFT
-template <int LOG2N, bool COLS, bool INV, int LOG2P>
+template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB = (kPoints >> LOG2N)>
 PAL_HD void stage_load(const cd* data, const cd* tw, int w, cd* v) {
   constexpr int R = stage_radix(LOG2N, LOG2P), N = 1 << LOG2N, P = 1 << LOG2P, NB = N / R;
   int i, t;
-  item_of<LOG2N, COLS, R>(w, i, t);
+  item_of<LOG2N, COLS, R, NSUB>(w, i, t);
 #pragma unroll
-  for (int r = 0; r < R; ++r) v[r] = data[lds_addr<LOG2N, COLS>(t, i + r * NB)];
+  for (int r = 0; r < R; ++r) v[r] = data[lds_addr<LOG2N, COLS, NSUB>(t, i + r * NB)];
   if (P > 1) {
     const int k = i & (P - 1);
     const cd* tws = tw + stage_tw_offset(LOG2N, LOG2P);
@@ -132,40 +132,72 @@ PAL_HD void stage_load(const cd* data, const cd* tw, int w, cd* v) {
 }
 
 // write the R outputs of work item w to their autosort positions
-template <int LOG2N, bool COLS, int LOG2P>
+template <int LOG2N, bool COLS, int LOG2P, int NSUB = (kPoints >> LOG2N)>
 PAL_HD void stage_store(cd* data, int w, const cd* v) {
   constexpr int R = stage_radix(LOG2N, LOG2P), P = 1 << LOG2P;
   int i, t;
-  item_of<LOG2N, COLS, R>(w, i, t);
+  item_of<LOG2N, COLS, R, NSUB>(w, i, t);
   const int k = i & (P - 1);
   const int j0 = (i - k) * R + k;
 #pragma unroll
-  for (int r = 0; r < R; ++r) data[lds_addr<LOG2N, COLS>(t, j0 + r * P)] = v[r];
+  for (int r = 0; r < R; ++r) data[lds_addr<LOG2N, COLS, NSUB>(t, j0 + r * P)] = v[r];
+}
+
+// ---------------------------------------------------------------- radix-3 outer stage (column mode)
+// A column transform of length 3N keeps its three length-N sub-sequences as sub-transforms q*T + c of the
+// LDS tile (T columns, NSUB = 3T).  Element e of sub-transform (q, c) is row  q*N + e  on the time side and
+// row  3e + q  on the frequency side, so one in-place 3-point butterfly per (e, c) links both sides:
+//   forward (decimation in frequency, before the N-point FFTs):  y_r[e] = w^(r e) sum_s w3^(r s) x[e + s N]
+//   inverse (after the inverse N-point FFTs):                    x[e + s N] = sum_r w3^(-r s) conj(w^(r e)) y_r[e]
+// with w = exp(-2 pi i / 3N) read from `roots` (exp(-2 pi i q / 3N), q < 3N) and w3 = exp(-2 pi i / 3).
+template <int LOG2N, int T, bool INV> PAL_HD void radix3_item(cd* data, const cd* roots, int w) {
+  constexpr int NSUB = 3 * T;
+  const int c = w % T, e = w / T;
+  cd a0 = data[lds_addr<LOG2N, true, NSUB>(c, e)];
+  cd a1 = data[lds_addr<LOG2N, true, NSUB>(T + c, e)];
+  cd a2 = data[lds_addr<LOG2N, true, NSUB>(2 * T + c, e)];
+  if (INV) {
+    a1 = cmulc(a1, roots[e]);
+    a2 = cmulc(a2, roots[2 * e]);
+  }
+  const double h = 0.86602540378443864676;            // sin(pi/3)
+  const cd sum = a1 + a2, dif = a1 - a2;
+  const cd mid = mk(a0.x - 0.5 * sum.x, a0.y - 0.5 * sum.y);
+  const cd rot = INV ? mk(-h * dif.y, h * dif.x) : mk(h * dif.y, -h * dif.x);   // (+/- i sqrt(3)/2) (a1 - a2)
+  cd y0 = a0 + sum, y1 = mid + rot, y2 = mid - rot;
+  if (!INV) {
+    y1 = cmul(y1, roots[e]);
+    y2 = cmul(y2, roots[2 * e]);
+  }
+  data[lds_addr<LOG2N, true, NSUB>(c, e)] = y0;
+  data[lds_addr<LOG2N, true, NSUB>(T + c, e)] = y1;
+  data[lds_addr<LOG2N, true, NSUB>(2 * T + c, e)] = y2;
 }
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------- workgroup transform (device)
-template <int LOG2N, bool COLS, bool INV, int LOG2P>
+template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB>
 __device__ __forceinline__ void wg_fft_from(cd* data, const cd* tw, int tid) {
   if constexpr (LOG2P < LOG2N) {
     constexpr int R = stage_radix(LOG2N, LOG2P);
-    constexpr int PER = kPoints / R / kLanes;        // work items per lane: 2, 4 or 8 (16 points per lane)
+    constexpr int POINTS = NSUB << LOG2N, LANES = POINTS / 16;   // 16 points per lane: 256 lanes (192 with a radix-3 stage)
+    constexpr int PER = POINTS / R / LANES;                      // work items per lane: 2, 4 or 8
     cd v[PER][R];
 #pragma unroll
-    for (int q = 0; q < PER; ++q) stage_load<LOG2N, COLS, INV, LOG2P>(data, tw, tid + kLanes * q, v[q]);
+    for (int q = 0; q < PER; ++q) stage_load<LOG2N, COLS, INV, LOG2P, NSUB>(data, tw, tid + LANES * q, v[q]);
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < PER; ++q) stage_store<LOG2N, COLS, LOG2P>(data, tid + kLanes * q, v[q]);
+    for (int q = 0; q < PER; ++q) stage_store<LOG2N, COLS, LOG2P, NSUB>(data, tid + LANES * q, v[q]);
     __syncthreads();
-    wg_fft_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P)>(data, tw, tid);
+    wg_fft_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P), NSUB>(data, tw, tid);
   }
 }
 
-// T = 4096/2^LOG2N transforms of length 2^LOG2N, in place in LDS; the caller has already
+// NSUB transforms of length 2^LOG2N (default 4096 points), in place in LDS; the caller has already
 // synchronised after filling `data` and `tw`, and the result is visible to all lanes on return.
-template <int LOG2N, bool COLS, bool INV>
+template <int LOG2N, bool COLS, bool INV, int NSUB = (kPoints >> LOG2N)>
 __device__ __forceinline__ void wg_fft(cd* data, const cd* tw, int tid) {
-  wg_fft_from<LOG2N, COLS, INV, 0>(data, tw, tid);
+  wg_fft_from<LOG2N, COLS, INV, 0, NSUB>(data, tw, tid);
 }
 #endif
 

@@ -191,6 +191,8 @@ int pal_create(int device, pal_handle* out) {
   if (env && atoi(env) > 0) e->chunk = atoi(env);
   env = getenv("PAL_OVERLAP");
   if (env) e->overlap = atoi(env) != 0;
+  env = getenv("PAL_RADIX3");
+  if (env) e->allow_r3 = atoi(env) != 0;
   *out = reinterpret_cast<pal_handle>(e);
   return PAL_OK;
 }
@@ -360,8 +362,8 @@ int pal_plan_info(pal_handle h, int L, int32_t* n, int32_t* conv_len, int32_t* m
   PAL_TRY(e->get_plan(2 * L - 1, L, 2 * L - 1, &pl));
   if (n) *n = pl->n;
   if (conv_len) *conv_len = int32_t(pl->inv.M());
-  if (m1) *m1 = 1 << pl->inv.l1;
-  if (m2) *m2 = 1 << pl->inv.l2;
+  if (m1) *m1 = pl->inv.M1();
+  if (m2) *m2 = pl->inv.M2();
   return PAL_OK;
 }
 

@@ -447,7 +447,7 @@ int pal_xcorr_vs_ref(pal_handle h, const double* rows_in, int R, int N, int ref_
   UP(dx, rows_in, size_t(R) * N * sizeof(double));
   const double* x = static_cast<double*>(dx);
   Conv c;
-  PAL_TRY(e->alloc_conv(c, ceil_log2(size_t(len))));
+  PAL_TRY(e->alloc_conv(c, size_t(len)));
   int rc = PAL_OK;
   do {
     RefLoader rl{x + size_t(ref_idx) * N, N};

@@ -22,15 +22,62 @@ static void make_stage_tw(int ln, std::vector<cd>& tw) {
   }
 }
 
-template <int LOG2N, bool COLS, bool INV, int LOG2P> static void emu_from(std::vector<cd>& data, const std::vector<cd>& tw) {
+template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB = (kPoints >> LOG2N)>
+static void emu_from(std::vector<cd>& data, const std::vector<cd>& tw) {
   if constexpr (LOG2P < LOG2N) {
     constexpr int R = stage_radix(LOG2N, LOG2P);
-    constexpr int ITEMS = kPoints / R;
+    constexpr int ITEMS = (NSUB << LOG2N) / R;
     std::vector<cd> regs(size_t(ITEMS) * R);
-    for (int w = 0; w < ITEMS; ++w) stage_load<LOG2N, COLS, INV, LOG2P>(data.data(), tw.data(), w, &regs[size_t(w) * R]);
-    for (int w = 0; w < ITEMS; ++w) stage_store<LOG2N, COLS, LOG2P>(data.data(), w, &regs[size_t(w) * R]);
-    emu_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P)>(data, tw);
+    for (int w = 0; w < ITEMS; ++w) stage_load<LOG2N, COLS, INV, LOG2P, NSUB>(data.data(), tw.data(), w, &regs[size_t(w) * R]);
+    for (int w = 0; w < ITEMS; ++w) stage_store<LOG2N, COLS, LOG2P, NSUB>(data.data(), w, &regs[size_t(w) * R]);
+    emu_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P), NSUB>(data, tw);
   }
+}
+
+// column transform of length 3N (radix-3 outer stage + N-point sub-transforms), T = 1024/N columns per tile
+template <int LOG2N, bool INV> static double check3() {
+  constexpr int N = 1 << LOG2N, T = 1024 / N, NSUB = 3 * T, M1 = 3 * N;
+  std::vector<cd> tw;
+  make_stage_tw(LOG2N, tw);
+  std::vector<cd> roots(M1);
+  for (int q = 0; q < M1; ++q) roots[q] = mk(std::cos(-2.0 * M_PI * q / M1), std::sin(-2.0 * M_PI * q / M1));
+  std::vector<cd> data(size_t(NSUB) << LOG2N), plain(size_t(T) * M1);
+  for (int c = 0; c < T; ++c)
+    for (int i = 0; i < M1; ++i) {
+      const cd v = mk(drand48() - 0.5, drand48() - 0.5);
+      plain[size_t(c) * M1 + i] = v;
+      // forward input: time side, row i = q N + e;  inverse input: frequency side, row i = 3 e + q
+      const int q = INV ? i % 3 : i / N, e = INV ? i / 3 : i % N;
+      data[lds_addr<LOG2N, true, NSUB>(q * T + c, e)] = v;
+    }
+  if (!INV)
+    for (int w = 0; w < N * T; ++w) radix3_item<LOG2N, T, false>(data.data(), roots.data(), w);
+  emu_from<LOG2N, true, INV, 0, NSUB>(data, tw);
+  if (INV)
+    for (int w = 0; w < N * T; ++w) radix3_item<LOG2N, T, true>(data.data(), roots.data(), w);
+  double worst = 0;
+  for (int c = 0; c < T; c += (T > 4 ? T / 4 : 1))
+    for (int o = 0; o < M1; ++o) {
+      long double sx = 0, sy = 0;
+      for (int i = 0; i < M1; ++i) {
+        const long double a = (INV ? 2.0L : -2.0L) * M_PIl * (long double)((long long)o * i % M1) / M1;
+        const long double cs = cosl(a), sn = sinl(a);
+        sx += plain[size_t(c) * M1 + i].x * cs - plain[size_t(c) * M1 + i].y * sn;
+        sy += plain[size_t(c) * M1 + i].x * sn + plain[size_t(c) * M1 + i].y * cs;
+      }
+      // forward output: frequency side, row o = 3 e + q;  inverse output: time side, row o = q N + e
+      const int q = INV ? o / N : o % 3, e = INV ? o % N : o / 3;
+      const cd got = data[lds_addr<LOG2N, true, NSUB>(q * T + c, e)];
+      worst = std::fmax(worst, std::fmax(std::fabs(double(got.x - sx)), std::fabs(double(got.y - sy))));
+    }
+  return worst / std::sqrt(double(M1));
+}
+
+template <int LOG2N> static int run3() {
+  const double f = check3<LOG2N, false>(), b = check3<LOG2N, true>();
+  const int bad = !(f < 1e-14) + !(b < 1e-14);
+  std::printf("3N=%5d cols fwd %.2e inv %.2e %s\n", 3 << LOG2N, f, b, bad ? "FAIL" : "ok");
+  return bad;
 }
 
 template <int LOG2N, bool COLS, bool INV> static double check() {
@@ -84,6 +131,11 @@ int main() {
   bad += run<9>();
   bad += run<10>();
   bad += run<11>();
+  bad += run3<4>();
+  bad += run3<5>();
+  bad += run3<6>();
+  bad += run3<7>();
+  bad += run3<8>();
   std::printf(bad ? "FAILED\n" : "ALL OK\n");
   return bad ? 1 : 0;
 }

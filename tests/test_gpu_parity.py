@@ -278,7 +278,7 @@ def test_localize_sound_source_position(golden, tmp_path, monkeypatch):
 
 def test_profile_counters_and_plan(engine):
     info = engine.plan_info(44100)
-    assert info["n"] == 88199 and info["conv_len"] == 262144 and info["m1"] * info["m2"] == 262144
+    assert info["n"] == 88199 and info["conv_len"] in (196608, 262144) and info["m1"] * info["m2"] == info["conv_len"]
     frames = np.random.default_rng(0).standard_normal((1, 4, 2000))
     engine.profile_begin()
     engine.gcc_phat_all_pairs(frames, 16000.0)
