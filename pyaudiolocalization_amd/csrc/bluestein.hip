@@ -257,52 +257,50 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, const int4* quads, in
   Engine* e = this;
   const Conv& c = pl.inv;
   const int n = pl.n;
+  // Launch groups alternate between two HIP streams, each with its own workspace and correlation buffer: the
+  // memory-bound head and tail of one group's kernels overlap the LDS/VALU-bound middle of the other's, and the
+  // peak kernel of group g runs beside the FFT passes of group g+1.  Same-slot reuse is ordered by the stream.
+  const bool two = overlap && table != nullptr;
+  const size_t wpoints = size_t(chunk) * c.M();
   void* wsp = nullptr;
-  PAL_TRY(scratch(0, size_t(chunk) * c.M() * sizeof(cd), &wsp));
+  PAL_TRY(scratch(0, (two ? 2 : 1) * wpoints * sizeof(cd), &wsp));
   cd* W = static_cast<cd*>(wsp);
   const size_t stride = corr_out ? size_t(n) : (size_t(n) + 1) & ~size_t(1);
-  // Two correlation buffers: the peak kernel of launch group g reads buffer g%2 on `stream2` while the three
-  // FFT passes of group g+1 fill the other one on `stream` (events order the hand-offs both ways).
   const size_t buf_doubles = size_t(2 * chunk) * stride;
   void* p = nullptr;
   PAL_TRY(scratch(1, 2 * buf_doubles * sizeof(double), &p));
   double* cbuf = static_cast<double*>(p);
-  const bool two = overlap && table != nullptr;
   const int64_t ntr = (npairs + 1) / 2;
+  if (two) {   // stream2 starts after everything already queued on `stream` (spectra, pair table)
+    PAL_HIP(hipEventRecord(ev_corr[0], stream));
+    PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[0], 0));
+  }
   int64_t group = 0;
-  bool used[2] = {false, false};
   for (int64_t t0 = 0; t0 < ntr; t0 += chunk, ++group) {
     const int G = int(ntr - t0 < chunk ? ntr - t0 : chunk);
     const int64_t p0 = 2 * t0;
     const int rows = int(npairs - p0 < 2 * G ? npairs - p0 : 2 * G);
-    const int slot = int(group & 1);
+    const int slot = two ? int(group & 1) : 0;
+    hipStream_t on = slot ? stream2 : stream;
+    cd* Wg = W + size_t(slot) * wpoints;
     // odd tail with a caller buffer: the imaginary half of the last transform has no destination row there
     const bool via_scratch = !corr_out || rows < 2 * G;
     double* crow = via_scratch ? cbuf + size_t(slot) * buf_doubles : corr_out + size_t(p0) * stride;
     PairLoader ld{spectra, quads + t0, n, pl.H, pl.w};
     CorrStorer st{crow, stride, n, pl.w};
-    PAL_TRY(launch_cols_fwd(e, c, G, ld, W));
-    PAL_TRY(launch_rows(e, c, G, W, true, 1.0));
-    if (two && via_scratch && used[slot]) PAL_HIP(hipStreamWaitEvent(stream, ev_peaks[slot], 0));   // buffer still being read?
-    PAL_TRY(launch_cols_inv(e, c, G, W, st));
+    PAL_TRY(launch_cols_fwd(e, c, G, ld, Wg, on));
+    PAL_TRY(launch_rows(e, c, G, Wg, true, 1.0, on));
+    PAL_TRY(launch_cols_inv(e, c, G, Wg, st, on));
     if (corr_out && via_scratch)
       PAL_HIP(hipMemcpyAsync(corr_out + size_t(p0) * stride, crow, size_t(rows) * stride * sizeof(double),
-                             hipMemcpyDeviceToDevice, stream));
-    if (!table) continue;
-    int32_t* km = ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr;
-    if (two) {
-      PAL_HIP(hipEventRecord(ev_corr[slot], stream));
-      PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[slot], 0));
-      PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, km, stream2));
-      PAL_HIP(hipEventRecord(ev_peaks[slot], stream2));
-      used[slot] = true;
-    } else {
-      PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, km, stream));
-    }
+                             hipMemcpyDeviceToDevice, on));
+    if (table)
+      PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr, on));
   }
-  if (two)   // whatever follows on `stream` (downloads, the RCCL gather) sees the finished table
-    for (int k = 0; k < 2; ++k)
-      if (used[k]) PAL_HIP(hipStreamWaitEvent(stream, ev_peaks[k], 0));
+  if (two) {   // whatever follows on `stream` (downloads, the RCCL gather) sees the finished table
+    PAL_HIP(hipEventRecord(ev_peaks[0], stream2));
+    PAL_HIP(hipStreamWaitEvent(stream, ev_peaks[0], 0));
+  }
   return PAL_OK;
 }
 

@@ -5,8 +5,12 @@
 // M2 (rows) is always a power of two.  M1 (columns) is 2^l1, or 3 * 2^l1 when the convolution length
 // is 3 * 2^k: all BASELINE frame lengths need 2n-1 = 0.73 * 2^k points, so the 3 * 2^(k-1) length cuts
 // a quarter of the HBM traffic of every pass.  The radix-3 column kernels run 192 lanes (3 wavefronts)
-// over 3072 points: one in-place 3-point butterfly stage in LDS (fft_core.h radix3_item) around the
-// same power-of-two sub-transforms.
+// over 3072 points: one 3-point butterfly stage (fft_core.h radix3_item) around the same power-of-two
+// sub-transforms.
+//
+// Every pass feeds the first FFT stage straight from global memory (or from the loader functor) and lets
+// the last stage write global memory (or call the storer functor): the only LDS traffic is the exchange
+// between stages.
 #pragma once
 #include "engine.h"
 
@@ -15,6 +19,96 @@ namespace pal {
 __global__ void k_make_chirp(cd* w, int n);
 __global__ void k_make_roots(cd* out, int count, double denom);
 __global__ void k_make_stage_tw(cd* out, int ln);
+
+// exp(-2 pi i e / M) for e < M from the two root tables (e = q * M2 + r)
+__device__ __forceinline__ cd four_step_twiddle(unsigned e, int l2, const cd* __restrict__ twA, const cd* __restrict__ twB) {
+  return cmul(twA[e >> l2], twB[e & ((1u << l2) - 1)]);
+}
+
+// ------------------------------------------------------------------ stage sources / sinks
+template <int L2> struct RowsGlobal {             // tile of 4096 consecutive points = 4096 / 2^L2 rows
+  static constexpr bool kLds = false;
+  cd* base;
+  __device__ cd operator()(int t, int e) const { return base[(t << L2) + e]; }
+  __device__ void operator()(int t, int e, cd v) const { base[(t << L2) + e] = v; }
+};
+
+template <int L2> struct RowsChatToLds {          // pointwise product with the chirp spectrum on the way into LDS
+  static constexpr bool kLds = true;
+  cd* data;
+  const cd* ch;
+  __device__ void operator()(int t, int e, cd v) const { data[lds_addr<L2, false>(t, e)] = cmul(v, ch[(t << L2) + e]); }
+};
+
+template <int L2> struct RowsScaled {             // forward-only rows (chirp-spectrum setup)
+  static constexpr bool kLds = false;
+  cd* base;
+  double scale;
+  __device__ void operator()(int t, int e, cd v) const { base[(t << L2) + e] = cscale(v, scale); }
+};
+
+template <class Loader> struct ColsFromLoader {   // column c0 + t, row e of the transform's input
+  static constexpr bool kLds = false;
+  const Loader& ld;
+  int g, l2;
+  unsigned c0;
+  __device__ cd operator()(int t, int e) const { return ld(g, (unsigned(e) << l2) + c0 + t); }
+};
+
+struct ColsToGlobal {                             // column FFT output (row k1 = e) times the four-step twiddle
+  static constexpr bool kLds = false;
+  cd* out;
+  int l2;
+  unsigned c0;
+  const cd *twA, *twB;
+  __device__ void operator()(int t, int e, cd v) const {
+    out[(size_t(e) << l2) + c0 + t] = cmul(v, four_step_twiddle((c0 + t) * unsigned(e), l2, twA, twB));
+  }
+};
+
+struct ColsFromGlobal {                           // inverse: row k1 = e times the conjugate twiddle
+  static constexpr bool kLds = false;
+  const cd* in;
+  int l2;
+  unsigned c0;
+  const cd *twA, *twB;
+  __device__ cd operator()(int t, int e) const {
+    return cmulc(in[(size_t(e) << l2) + c0 + t], four_step_twiddle((c0 + t) * unsigned(e), l2, twA, twB));
+  }
+};
+
+template <class Storer> struct ColsToStorer {
+  static constexpr bool kLds = false;
+  const Storer& st;
+  int g, l2;
+  unsigned c0;
+  __device__ void operator()(int t, int e, cd v) const { st(g, (unsigned(e) << l2) + c0 + t, v); }
+};
+
+// radix-3 column passes: sub-transform t = q * T + c, element e  <->  frequency row k1 = 3e + q
+template <int T> struct Cols3ToGlobal {
+  static constexpr bool kLds = false;
+  cd* out;
+  int l2;
+  unsigned c0;
+  const cd *twA, *twB;
+  __device__ void operator()(int t, int e, cd v) const {
+    const unsigned k1 = 3u * unsigned(e) + unsigned(t / T), c = c0 + unsigned(t % T);
+    out[(size_t(k1) << l2) + c] = cmul(v, four_step_twiddle(c * k1, l2, twA, twB));
+  }
+};
+
+template <int T> struct Cols3FromGlobal {
+  static constexpr bool kLds = false;
+  const cd* in;
+  int l2;
+  unsigned c0;
+  const cd *twA, *twB;
+  __device__ cd operator()(int t, int e) const {
+    const unsigned k1 = 3u * unsigned(e) + unsigned(t / T), c = c0 + unsigned(t % T);
+    return cmulc(in[(size_t(k1) << l2) + c], four_step_twiddle(c * k1, l2, twA, twB));
+  }
+};
 
 // ------------------------------------------------------------------ the three passes (M1 = 2^L1)
 // Each workgroup (256 lanes) owns 4096 points.  Grid = G * M / 4096, transform index fastest so that
@@ -30,29 +124,15 @@ __global__ __launch_bounds__(256) void k_cols_fwd(Loader ld, cd* __restrict__ W,
   const int g = blockIdx.x % G;
   const unsigned c0 = (blockIdx.x / G) * T;
   for (int i = tid; i < stage_tw_size(L1); i += kLanes) tw[i] = tws[i];
-#pragma unroll
-  for (int q = 0; q < kPoints / kLanes; ++q) {
-    const unsigned idx = tid + kLanes * q, c = idx % T, j1 = idx / T;
-    data[idx] = ld(g, (j1 << l2) + c0 + c);
-  }
-  __syncthreads();
-  wg_fft<L1, true, false>(data, tw, tid);
-  cd* out = W + (size_t(g) << (L1 + l2));
-  const unsigned mask = (1u << l2) - 1;
-#pragma unroll
-  for (int q = 0; q < kPoints / kLanes; ++q) {
-    const unsigned idx = tid + kLanes * q, c = idx % T, k1 = idx / T;
-    const unsigned e = (c0 + c) * k1;                       // < M
-    const cd f = cmul(twA[e >> l2], twB[e & mask]);        // exp(-2 pi i e / M)
-    out[(size_t(k1) << l2) + c0 + c] = cmul(data[idx], f);
-  }
+  wg_fft<L1, true, false, T>(data, tw, tid, ColsFromLoader<Loader>{ld, g, l2, c0},
+                             ColsToGlobal{W + (size_t(g) << (L1 + l2)), l2, c0, twA, twB});
 }
 
 // rows of length 2^L2; `m` = points per transform (any multiple of 4096)
 template <int L2, bool CONV>
 __global__ __launch_bounds__(256) void k_rows(cd* __restrict__ W, const cd* __restrict__ chat, size_t m, int G,
                                               const cd* __restrict__ tws, double scale) {
-  constexpr int N2 = 1 << L2;
+  constexpr int N2 = 1 << L2, T = kPoints / N2;
   __shared__ cd data[kPoints];
   __shared__ cd tw[N2];
   const int tid = threadIdx.x;
@@ -60,34 +140,11 @@ __global__ __launch_bounds__(256) void k_rows(cd* __restrict__ W, const cd* __re
   const size_t tile = blockIdx.x / G;                       // 4096 consecutive points = 4096/N2 rows
   for (int i = tid; i < stage_tw_size(L2); i += kLanes) tw[i] = tws[i];
   cd* base = W + size_t(g) * m + tile * kPoints;
-#pragma unroll
-  for (int q = 0; q < kPoints / kLanes; ++q) {
-    const int idx = tid + kLanes * q;
-    data[lds_addr<L2, false>(idx >> L2, idx & (N2 - 1))] = base[idx];
-  }
-  __syncthreads();
-  wg_fft<L2, false, false>(data, tw, tid);
   if (CONV) {
-    const cd* ch = chat + tile * kPoints;
-#pragma unroll
-    for (int q = 0; q < kPoints / kLanes; ++q) {
-      const int idx = tid + kLanes * q;
-      const int a = lds_addr<L2, false>(idx >> L2, idx & (N2 - 1));
-      data[a] = cmul(data[a], ch[idx]);
-    }
-    __syncthreads();
-    wg_fft<L2, false, true>(data, tw, tid);
-#pragma unroll
-    for (int q = 0; q < kPoints / kLanes; ++q) {
-      const int idx = tid + kLanes * q;
-      base[idx] = data[lds_addr<L2, false>(idx >> L2, idx & (N2 - 1))];
-    }
+    wg_fft<L2, false, false, T>(data, tw, tid, RowsGlobal<L2>{base}, RowsChatToLds<L2>{data, chat + tile * kPoints});
+    wg_fft<L2, false, true, T>(data, tw, tid, LdsTile<L2, false, T>{data}, RowsGlobal<L2>{base});
   } else {
-#pragma unroll
-    for (int q = 0; q < kPoints / kLanes; ++q) {
-      const int idx = tid + kLanes * q;
-      base[idx] = cscale(data[lds_addr<L2, false>(idx >> L2, idx & (N2 - 1))], scale);
-    }
+    wg_fft<L2, false, false, T>(data, tw, tid, RowsGlobal<L2>{base}, RowsScaled<L2>{base, scale});
   }
 }
 
@@ -102,22 +159,8 @@ __global__ __launch_bounds__(256) void k_cols_inv(const cd* __restrict__ W, Stor
   const int g = blockIdx.x % G;
   const unsigned c0 = (blockIdx.x / G) * T;
   for (int i = tid; i < stage_tw_size(L1); i += kLanes) tw[i] = tws[i];
-  const cd* in = W + (size_t(g) << (L1 + l2));
-  const unsigned mask = (1u << l2) - 1;
-#pragma unroll
-  for (int q = 0; q < kPoints / kLanes; ++q) {
-    const unsigned idx = tid + kLanes * q, c = idx % T, k1 = idx / T;
-    const unsigned e = (c0 + c) * k1;
-    const cd f = cmul(twA[e >> l2], twB[e & mask]);
-    data[idx] = cmulc(in[(size_t(k1) << l2) + c0 + c], f);   // times exp(+2 pi i e / M)
-  }
-  __syncthreads();
-  wg_fft<L1, true, true>(data, tw, tid);
-#pragma unroll
-  for (int q = 0; q < kPoints / kLanes; ++q) {
-    const unsigned idx = tid + kLanes * q, c = idx % T, j1 = idx / T;
-    st(g, (j1 << l2) + c0 + c, data[idx]);
-  }
+  wg_fft<L1, true, true, T>(data, tw, tid, ColsFromGlobal{W + (size_t(g) << (L1 + l2)), l2, c0, twA, twB},
+                            ColsToStorer<Storer>{st, g, l2, c0});
 }
 
 // ------------------------------------------------------------------ column passes for M1 = 3 * 2^LN
@@ -136,24 +179,12 @@ __global__ __launch_bounds__(192) void k_cols3_fwd(Loader ld, cd* __restrict__ W
   const int g = blockIdx.x % G;
   const unsigned c0 = (blockIdx.x / G) * T;
   for (int i = tid; i < stage_tw_size(LN); i += kLanes3) tw[i] = tws[i];
-#pragma unroll
-  for (int q = 0; q < kPoints3 / kLanes3; ++q) {
-    const unsigned idx = tid + kLanes3 * q, c = idx % T, j1 = idx / T;      // j1 < 3N
-    data[lds_addr<LN, true, NSUB>((j1 >> LN) * T + c, j1 & (N - 1))] = ld(g, (j1 << l2) + c0 + c);
-  }
+  const auto rows3 = [&](int q, int c, int e) { return ld(g, (unsigned(q * N + e) << l2) + c0 + c); };
+  const LdsTile3<LN, T> tile3{data};
+  for (int w = tid; w < N * T; w += kLanes3) radix3_item<T, false>(rows3, tile3, twA, w);
   __syncthreads();
-  for (int w = tid; w < N * T; w += kLanes3) radix3_item<LN, T, false>(data, twA, w);
-  __syncthreads();
-  wg_fft<LN, true, false, NSUB>(data, tw, tid);
-  cd* out = W + size_t(g) * (size_t(3 * N) << l2);
-  const unsigned mask = (1u << l2) - 1;
-#pragma unroll
-  for (int q = 0; q < kPoints3 / kLanes3; ++q) {
-    const unsigned idx = tid + kLanes3 * q, c = idx % T, k1 = idx / T;      // k1 = 3e + r
-    const unsigned e = (c0 + c) * k1;
-    const cd f = cmul(twA[e >> l2], twB[e & mask]);
-    out[(size_t(k1) << l2) + c0 + c] = cmul(data[lds_addr<LN, true, NSUB>((k1 % 3) * T + c, k1 / 3)], f);
-  }
+  wg_fft<LN, true, false, NSUB>(data, tw, tid, LdsTile<LN, true, NSUB>{data},
+                                Cols3ToGlobal<T>{W + size_t(g) * (size_t(3 * N) << l2), l2, c0, twA, twB});
 }
 
 template <int LN, class Storer>
@@ -167,24 +198,11 @@ __global__ __launch_bounds__(192) void k_cols3_inv(const cd* __restrict__ W, Sto
   const int g = blockIdx.x % G;
   const unsigned c0 = (blockIdx.x / G) * T;
   for (int i = tid; i < stage_tw_size(LN); i += kLanes3) tw[i] = tws[i];
-  const cd* in = W + size_t(g) * (size_t(3 * N) << l2);
-  const unsigned mask = (1u << l2) - 1;
-#pragma unroll
-  for (int q = 0; q < kPoints3 / kLanes3; ++q) {
-    const unsigned idx = tid + kLanes3 * q, c = idx % T, k1 = idx / T;
-    const unsigned e = (c0 + c) * k1;
-    const cd f = cmul(twA[e >> l2], twB[e & mask]);
-    data[lds_addr<LN, true, NSUB>((k1 % 3) * T + c, k1 / 3)] = cmulc(in[(size_t(k1) << l2) + c0 + c], f);
-  }
-  __syncthreads();
-  wg_fft<LN, true, true, NSUB>(data, tw, tid);
-  for (int w = tid; w < N * T; w += kLanes3) radix3_item<LN, T, true>(data, twA, w);
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < kPoints3 / kLanes3; ++q) {
-    const unsigned idx = tid + kLanes3 * q, c = idx % T, j1 = idx / T;
-    st(g, (j1 << l2) + c0 + c, data[lds_addr<LN, true, NSUB>((j1 >> LN) * T + c, j1 & (N - 1))]);
-  }
+  wg_fft<LN, true, true, NSUB>(data, tw, tid, Cols3FromGlobal<T>{W + size_t(g) * (size_t(3 * N) << l2), l2, c0, twA, twB},
+                               LdsTile<LN, true, NSUB>{data});
+  const LdsTile3<LN, T> tile3{data};
+  const auto rows3 = [&](int q, int c, int e, cd v) { st(g, (unsigned(q * N + e) << l2) + c0 + c, v); };
+  for (int w = tid; w < N * T; w += kLanes3) radix3_item<T, true>(tile3, rows3, twA, w);
 }
 
 // ------------------------------------------------------------------ launch helpers
@@ -210,47 +228,50 @@ __global__ __launch_bounds__(192) void k_cols3_inv(const cd* __restrict__ W, Sto
   }
 
 template <class Loader>
-static int launch_cols_fwd(Engine* e, const Conv& c, int G, Loader ld, cd* W) {
+static int launch_cols_fwd(Engine* e, const Conv& c, int G, Loader ld, cd* W, hipStream_t on = nullptr) {
+  if (!on) on = e->stream;
   char name[64];
   snprintf(name, sizeof name, "k_cols%s_fwd<%d,%s>", c.r3 ? "3" : "", c.l1, Loader::kName);
-  ProfScope ps(e, name);
+  ProfScope ps(e, name, on);
   if (c.r3) {
     const unsigned grid = unsigned(size_t(G) * (c.M() / kPoints3));
-    PAL_SWITCH_L3(c.l1, k_cols3_fwd<LL, Loader><<<dim3(grid), dim3(kLanes3), 0, e->stream>>>(ld, W, c.l2, G, e->stage_table(LL),
+    PAL_SWITCH_L3(c.l1, k_cols3_fwd<LL, Loader><<<dim3(grid), dim3(kLanes3), 0, on>>>(ld, W, c.l2, G, e->stage_table(LL),
                                                                                               c.twA, c.twB));
   } else {
     const unsigned grid = unsigned(size_t(G) * (c.M() / kPoints));
-    PAL_SWITCH_L(c.l1, k_cols_fwd<LL, Loader><<<dim3(grid), dim3(kLanes), 0, e->stream>>>(ld, W, c.l2, G, e->stage_table(LL),
+    PAL_SWITCH_L(c.l1, k_cols_fwd<LL, Loader><<<dim3(grid), dim3(kLanes), 0, on>>>(ld, W, c.l2, G, e->stage_table(LL),
                                                                                           c.twA, c.twB));
   }
   return e->check(hipGetLastError(), "k_cols_fwd");
 }
 
-static int launch_rows(Engine* e, const Conv& c, int G, cd* W, bool conv, double scale) {
+static int launch_rows(Engine* e, const Conv& c, int G, cd* W, bool conv, double scale, hipStream_t on = nullptr) {
+  if (!on) on = e->stream;
   char name[64];
   snprintf(name, sizeof name, "k_rows<%d,%s>", c.l2, conv ? "conv" : "fwd");
-  ProfScope ps(e, name);
+  ProfScope ps(e, name, on);
   const unsigned grid = unsigned(size_t(G) * (c.M() / kPoints));
   if (conv) {
-    PAL_SWITCH_L(c.l2, k_rows<LL, true><<<dim3(grid), dim3(kLanes), 0, e->stream>>>(W, c.chat, c.M(), G, e->stage_table(LL), scale));
+    PAL_SWITCH_L(c.l2, k_rows<LL, true><<<dim3(grid), dim3(kLanes), 0, on>>>(W, c.chat, c.M(), G, e->stage_table(LL), scale));
   } else {
-    PAL_SWITCH_L(c.l2, k_rows<LL, false><<<dim3(grid), dim3(kLanes), 0, e->stream>>>(W, c.chat, c.M(), G, e->stage_table(LL), scale));
+    PAL_SWITCH_L(c.l2, k_rows<LL, false><<<dim3(grid), dim3(kLanes), 0, on>>>(W, c.chat, c.M(), G, e->stage_table(LL), scale));
   }
   return e->check(hipGetLastError(), "k_rows");
 }
 
 template <class Storer>
-static int launch_cols_inv(Engine* e, const Conv& c, int G, const cd* W, Storer st) {
+static int launch_cols_inv(Engine* e, const Conv& c, int G, const cd* W, Storer st, hipStream_t on = nullptr) {
+  if (!on) on = e->stream;
   char name[64];
   snprintf(name, sizeof name, "k_cols%s_inv<%d,%s>", c.r3 ? "3" : "", c.l1, Storer::kName);
-  ProfScope ps(e, name);
+  ProfScope ps(e, name, on);
   if (c.r3) {
     const unsigned grid = unsigned(size_t(G) * (c.M() / kPoints3));
-    PAL_SWITCH_L3(c.l1, k_cols3_inv<LL, Storer><<<dim3(grid), dim3(kLanes3), 0, e->stream>>>(W, st, c.l2, G, e->stage_table(LL),
+    PAL_SWITCH_L3(c.l1, k_cols3_inv<LL, Storer><<<dim3(grid), dim3(kLanes3), 0, on>>>(W, st, c.l2, G, e->stage_table(LL),
                                                                                               c.twA, c.twB));
   } else {
     const unsigned grid = unsigned(size_t(G) * (c.M() / kPoints));
-    PAL_SWITCH_L(c.l1, k_cols_inv<LL, Storer><<<dim3(grid), dim3(kLanes), 0, e->stream>>>(W, st, c.l2, G, e->stage_table(LL),
+    PAL_SWITCH_L(c.l1, k_cols_inv<LL, Storer><<<dim3(grid), dim3(kLanes), 0, on>>>(W, st, c.l2, G, e->stage_table(LL),
                                                                                           c.twA, c.twB));
   }
   return e->check(hipGetLastError(), "k_cols_inv");

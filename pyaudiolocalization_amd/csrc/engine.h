@@ -50,10 +50,10 @@ struct Engine {
   hipStream_t stream = nullptr;    // FFT passes, copies, everything a caller can order against
   hipStream_t stream2 = nullptr;   // peak selection of launch group g while the passes of g+1 run on `stream`
   hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams
-  bool overlap = true;
+  bool overlap = false;            // PAL_OVERLAP=1: alternate launch groups between the two streams (no gain measured)
   bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
   std::string err;
-  int chunk = 64;                               // transforms per launch group (W = 64 x 3 MB stays in the 256 MiB Infinity Cache)
+  int chunk = 128;                              // transforms per launch group (256 PHAT rows per peak-kernel launch: one per CU)
   std::map<std::tuple<int, int, int>, Plan> plans;   // (n, lin, nout) -> plan
   cd* stage_tw[12] = {};                        // stage-major twiddles per log2 N
   // growable device scratch

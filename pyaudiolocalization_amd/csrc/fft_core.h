@@ -2,12 +2,16 @@
 //
 // The reference computes every transform with numpy.fft at the exact, non-smooth length
 // n = n1+n2-1 (utils.py:113-118) or 2N (signal_processing.py:68-72).  On the GPU an exact
-// length-n DFT is a Bluestein chirp convolution over a power-of-two length M that is cut
-// four-step style into M = M1 x M2 with both sub-transforms resident in LDS:
+// length-n DFT is a Bluestein chirp convolution over a length M = M1 x M2 (2^k or 3 * 2^k) that is cut
+// four-step style so that both sub-transforms are resident in LDS:
 //
-//   a workgroup of 256 lanes (4 wavefronts of 64) owns 4096 complex doubles (64 KiB of LDS)
-//   = T = 4096/N independent length-N sub-FFTs, Stockham autosort, radix 8 (+ one radix 4/2
-//   tail), 16 points per lane in registers, two barriers per stage, in place.
+//   a workgroup owns NSUB independent length-N sub-FFTs (4096 points / 256 lanes, or 3072 / 192 with
+//   a radix-3 column stage), Stockham autosort, radix 16 / 8 (+ a radix 4 / 2 tail), 16 points per
+//   lane in registers, in place.  The FIRST stage reads its inputs through a functor (global memory,
+//   or a loader that builds the input on the fly) and the LAST stage hands its outputs to a functor
+//   (global memory, a storer, or LDS with a pointwise multiply), so a transform costs one LDS round
+//   trip per stage boundary and none for staging - LDS stores (about 80 B/clk/CU) are the scarce
+//   resource of these kernels, not the butterflies.
 //
 // Index math lives in __host__ __device__ functions so tests/host/test_fft_core.cpp can
 // execute the identical stage code lane by lane on the CPU.
@@ -36,8 +40,13 @@ PAL_HD cd cscale(cd a, double s) { return mk(a.x * s, a.y * s); }
 
 // multiply by -i (forward transform) or +i (inverse transform)
 template <bool INV> PAL_HD cd rot90(cd a) { return INV ? mk(-a.y, a.x) : mk(a.y, -a.x); }
+// multiply by exp(-/+ 2 pi i * (cos, sin pair given for the forward direction))
+template <bool INV> PAL_HD cd rotc(cd a, double c, double s) {   // forward factor = (c, -s)
+  return INV ? mk(__builtin_fma(a.x, c, -(a.y * s)), __builtin_fma(a.x, s, a.y * c))
+             : mk(__builtin_fma(a.x, c, a.y * s), __builtin_fma(a.y, c, -(a.x * s)));
+}
 
-constexpr int kPoints = 4096;   // complex points per workgroup
+constexpr int kPoints = 4096;   // complex points per workgroup (power-of-two passes)
 constexpr int kLanes = 256;     // lanes per workgroup (4 wavefronts)
 
 // ---------------------------------------------------------------- small DFTs, in registers
@@ -62,9 +71,9 @@ template <bool INV> PAL_HD void dft8(cd* v) {
   dft4<INV>(e);
   dft4<INV>(o);
   // o[k] *= exp(-/+ 2 pi i k / 8)
-  cd o1 = INV ? mk((o[1].x - o[1].y) * h, (o[1].x + o[1].y) * h) : mk((o[1].x + o[1].y) * h, (o[1].y - o[1].x) * h);
+  cd o1 = rotc<INV>(o[1], h, h);
   cd o2 = rot90<INV>(o[2]);
-  cd o3 = INV ? mk((-o[3].x - o[3].y) * h, (o[3].x - o[3].y) * h) : mk((o[3].y - o[3].x) * h, (-o[3].x - o[3].y) * h);
+  cd o3 = rotc<INV>(o[3], -h, h);
   v[0] = e[0] + o[0];
   v[4] = e[0] - o[0];
   v[1] = e[1] + o1;
@@ -75,16 +84,52 @@ template <bool INV> PAL_HD void dft8(cd* v) {
   v[7] = e[3] - o3;
 }
 
+// 16 = 4 x 4: input n = 4a + b, output k = c + 4d;  X[c + 4d] = sum_b W4^(bd) W16^(bc) sum_a W4^(ac) x[4a + b]
+template <bool INV> PAL_HD void dft16(cd* v) {
+  const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173;   // cos, sin of pi/8
+  const double h = 0.70710678118654752440;
+  cd u[4][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    cd t[4] = {v[b], v[4 + b], v[8 + b], v[12 + b]};
+    dft4<INV>(t);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) u[b][c] = t[c];
+  }
+  u[1][1] = rotc<INV>(u[1][1], c1, s1);     // W16^1
+  u[1][2] = rotc<INV>(u[1][2], h, h);       // W16^2
+  u[1][3] = rotc<INV>(u[1][3], s1, c1);     // W16^3
+  u[2][1] = rotc<INV>(u[2][1], h, h);       // W16^2
+  u[2][2] = rot90<INV>(u[2][2]);            // W16^4
+  u[2][3] = rotc<INV>(u[2][3], -h, h);      // W16^6
+  u[3][1] = rotc<INV>(u[3][1], s1, c1);     // W16^3
+  u[3][2] = rotc<INV>(u[3][2], -h, h);      // W16^6
+  u[3][3] = rotc<INV>(u[3][3], -c1, -s1);   // W16^9
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    cd t[4] = {u[0][c], u[1][c], u[2][c], u[3][c]};
+    dft4<INV>(t);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) v[c + 4 * d] = t[d];
+  }
+}
+
 template <int R, bool INV> PAL_HD void dftR(cd* v) {
-  if (R == 8) dft8<INV>(v);
+  if (R == 16) dft16<INV>(v);
+  else if (R == 8) dft8<INV>(v);
   else if (R == 4) dft4<INV>(v);
   else dft2<INV>(v);
 }
 
 // ---------------------------------------------------------------- stage plan
-// radix of the stage that starts at log2(P) = lp in a length-2^ln transform: 8 while >= 3 bits remain.
-PAL_HD constexpr int stage_radix(int ln, int lp) { return (ln - lp) >= 3 ? 8 : ((ln - lp) == 2 ? 4 : 2); }
-PAL_HD constexpr int stage_log2r(int ln, int lp) { return (ln - lp) >= 3 ? 3 : (ln - lp); }
+// log2 of the radix of the stage that starts with lp bits done in a length-2^ln transform: 16 when exactly
+// four or at least seven bits remain, else 8, then a 4 / 2 tail:  4:[16] 5:[8,4] 6:[8,8] 7:[16,8] 8:[16,16]
+// 9:[16,8,4] 10:[16,8,8] 11:[16,16,8]
+PAL_HD constexpr int stage_log2r(int ln, int lp) {
+  return (ln - lp) == 4 || (ln - lp) >= 7 ? 4 : ((ln - lp) >= 3 ? 3 : (ln - lp));
+}
+PAL_HD constexpr int stage_radix(int ln, int lp) { return 1 << stage_log2r(ln, lp); }
+PAL_HD constexpr bool stage_is_last(int ln, int lp) { return lp + stage_log2r(ln, lp) >= ln; }
 
 // Stage-major twiddle table: for every stage with P > 1, entries [(r-1)*P + k] = exp(-2 pi i k r / (P R)),
 // k < P, 1 <= r < R, so that the lanes of a wavefront (consecutive k) read consecutive entries.
@@ -96,29 +141,36 @@ PAL_HD constexpr int stage_tw_offset(int ln, int lp) {
 PAL_HD constexpr int stage_tw_size(int ln) { return stage_tw_offset(ln, ln); }   // < 2^ln
 
 // LDS address of element e of sub-transform t.
-//   COLS: t fastest (lanes of a wavefront walk the T columns of a tile, the copy to and from global
-//         memory keeps the same order, no conflicts for T >= 8).
-//   ROWS: e fastest with an XOR swizzle of the low three bits by the next three, which spreads the
-//         stride-8 writes of the first radix-8 stage over all banks.
+//   COLS: t fastest (lanes of a wavefront walk the columns of a tile, no conflicts for >= 8 columns).
+//   ROWS: e fastest with an XOR swizzle of the low three bits by bits 3..5 and 6..8, which spreads the
+//         stride-16 / stride-8 stores of the first stage over all banks.
 template <int LOG2N, bool COLS, int NSUB = (kPoints >> LOG2N)> PAL_HD int lds_addr(int t, int e) {
   constexpr int N = 1 << LOG2N;
-  return COLS ? e * NSUB + t : t * N + (e ^ ((e >> 3) & 7));
+  return COLS ? e * NSUB + t : t * N + (e ^ (((e >> 3) ^ (e >> 6)) & 7));
 }
 
-// work item w in [0, 4096/R) -> (butterfly i, sub-transform t)
+// element accessors of the in-LDS tile (the default source / sink of a stage)
+template <int LOG2N, bool COLS, int NSUB = (kPoints >> LOG2N)> struct LdsTile {
+  static constexpr bool kLds = true;
+  cd* data;
+  PAL_HD cd operator()(int t, int e) const { return data[lds_addr<LOG2N, COLS, NSUB>(t, e)]; }
+  PAL_HD void operator()(int t, int e, cd v) const { data[lds_addr<LOG2N, COLS, NSUB>(t, e)] = v; }
+};
+
+// work item w in [0, POINTS/R) -> (butterfly i, sub-transform t)
 template <int LOG2N, bool COLS, int R, int NSUB = (kPoints >> LOG2N)> PAL_HD void item_of(int w, int& i, int& t) {
   constexpr int N = 1 << LOG2N, NB = N / R;
   if (COLS) { t = w % NSUB; i = w / NSUB; } else { i = w % NB; t = w / NB; }
 }
 
-// read the R inputs of work item w, apply the stage twiddles, run the radix-R DFT
-template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB = (kPoints >> LOG2N)>
-PAL_HD void stage_load(const cd* data, const cd* tw, int w, cd* v) {
+// read the R inputs of work item w through `in(t, e)`, apply the stage twiddles, run the radix-R DFT
+template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB, class In>
+PAL_HD void stage_load(const In& in, const cd* tw, int w, cd* v) {
   constexpr int R = stage_radix(LOG2N, LOG2P), N = 1 << LOG2N, P = 1 << LOG2P, NB = N / R;
   int i, t;
   item_of<LOG2N, COLS, R, NSUB>(w, i, t);
 #pragma unroll
-  for (int r = 0; r < R; ++r) v[r] = data[lds_addr<LOG2N, COLS, NSUB>(t, i + r * NB)];
+  for (int r = 0; r < R; ++r) v[r] = in(t, i + r * NB);
   if (P > 1) {
     const int k = i & (P - 1);
     const cd* tws = tw + stage_tw_offset(LOG2N, LOG2P);
@@ -131,31 +183,30 @@ PAL_HD void stage_load(const cd* data, const cd* tw, int w, cd* v) {
   dftR<R, INV>(v);
 }
 
-// write the R outputs of work item w to their autosort positions
-template <int LOG2N, bool COLS, int LOG2P, int NSUB = (kPoints >> LOG2N)>
-PAL_HD void stage_store(cd* data, int w, const cd* v) {
+// hand the R outputs of work item w to `out(t, e, value)` at their autosort positions
+template <int LOG2N, bool COLS, int LOG2P, int NSUB, class Out>
+PAL_HD void stage_store(const Out& out, int w, const cd* v) {
   constexpr int R = stage_radix(LOG2N, LOG2P), P = 1 << LOG2P;
   int i, t;
   item_of<LOG2N, COLS, R, NSUB>(w, i, t);
   const int k = i & (P - 1);
   const int j0 = (i - k) * R + k;
 #pragma unroll
-  for (int r = 0; r < R; ++r) data[lds_addr<LOG2N, COLS, NSUB>(t, j0 + r * P)] = v[r];
+  for (int r = 0; r < R; ++r) out(t, j0 + r * P, v[r]);
 }
 
 // ---------------------------------------------------------------- radix-3 outer stage (column mode)
 // A column transform of length 3N keeps its three length-N sub-sequences as sub-transforms q*T + c of the
 // LDS tile (T columns, NSUB = 3T).  Element e of sub-transform (q, c) is row  q*N + e  on the time side and
-// row  3e + q  on the frequency side, so one in-place 3-point butterfly per (e, c) links both sides:
+// row  3e + q  on the frequency side, so one 3-point butterfly per (e, c) links both sides:
 //   forward (decimation in frequency, before the N-point FFTs):  y_r[e] = w^(r e) sum_s w3^(r s) x[e + s N]
 //   inverse (after the inverse N-point FFTs):                    x[e + s N] = sum_r w3^(-r s) conj(w^(r e)) y_r[e]
 // with w = exp(-2 pi i / 3N) read from `roots` (exp(-2 pi i q / 3N), q < 3N) and w3 = exp(-2 pi i / 3).
-template <int LOG2N, int T, bool INV> PAL_HD void radix3_item(cd* data, const cd* roots, int w) {
-  constexpr int NSUB = 3 * T;
+// `in(q, c, e)` supplies the three inputs and `out(q, c, e, value)` takes the three outputs.
+template <int T, bool INV, class In, class Out>
+PAL_HD void radix3_item(const In& in, const Out& out, const cd* roots, int w) {
   const int c = w % T, e = w / T;
-  cd a0 = data[lds_addr<LOG2N, true, NSUB>(c, e)];
-  cd a1 = data[lds_addr<LOG2N, true, NSUB>(T + c, e)];
-  cd a2 = data[lds_addr<LOG2N, true, NSUB>(2 * T + c, e)];
+  cd a0 = in(0, c, e), a1 = in(1, c, e), a2 = in(2, c, e);
   if (INV) {
     a1 = cmulc(a1, roots[e]);
     a2 = cmulc(a2, roots[2 * e]);
@@ -169,35 +220,55 @@ template <int LOG2N, int T, bool INV> PAL_HD void radix3_item(cd* data, const cd
     y1 = cmul(y1, roots[e]);
     y2 = cmul(y2, roots[2 * e]);
   }
-  data[lds_addr<LOG2N, true, NSUB>(c, e)] = y0;
-  data[lds_addr<LOG2N, true, NSUB>(T + c, e)] = y1;
-  data[lds_addr<LOG2N, true, NSUB>(2 * T + c, e)] = y2;
+  out(0, c, e, y0);
+  out(1, c, e, y1);
+  out(2, c, e, y2);
 }
+
+// the (q, c, e) view of an LDS tile with NSUB = 3T sub-transforms
+template <int LOG2N, int T> struct LdsTile3 {
+  cd* data;
+  PAL_HD cd operator()(int q, int c, int e) const { return data[lds_addr<LOG2N, true, 3 * T>(q * T + c, e)]; }
+  PAL_HD void operator()(int q, int c, int e, cd v) const { data[lds_addr<LOG2N, true, 3 * T>(q * T + c, e)] = v; }
+};
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------- workgroup transform (device)
-template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB>
-__device__ __forceinline__ void wg_fft_from(cd* data, const cd* tw, int tid) {
+template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB, class FirstIn, class LastOut>
+__device__ __forceinline__ void wg_fft_from(cd* data, const cd* tw, int tid, const FirstIn& first, const LastOut& last) {
   if constexpr (LOG2P < LOG2N) {
     constexpr int R = stage_radix(LOG2N, LOG2P);
     constexpr int POINTS = NSUB << LOG2N, LANES = POINTS / 16;   // 16 points per lane: 256 lanes (192 with a radix-3 stage)
-    constexpr int PER = POINTS / R / LANES;                      // work items per lane: 2, 4 or 8
+    constexpr int PER = POINTS / R / LANES;                      // work items per lane: 1, 2, 4 or 8
+    constexpr bool kFirst = LOG2P == 0, kLast = stage_is_last(LOG2N, LOG2P);
+    constexpr bool in_lds = !kFirst || FirstIn::kLds, out_lds = !kLast || LastOut::kLds;
+    const LdsTile<LOG2N, COLS, NSUB> tile{data};
     cd v[PER][R];
 #pragma unroll
-    for (int q = 0; q < PER; ++q) stage_load<LOG2N, COLS, INV, LOG2P, NSUB>(data, tw, tid + LANES * q, v[q]);
-    __syncthreads();
+    for (int q = 0; q < PER; ++q) {
+      if constexpr (kFirst) stage_load<LOG2N, COLS, INV, LOG2P, NSUB>(first, tw, tid + LANES * q, v[q]);
+      else stage_load<LOG2N, COLS, INV, LOG2P, NSUB>(tile, tw, tid + LANES * q, v[q]);
+    }
+    if constexpr (in_lds && out_lds) __syncthreads();            // in place: every read before any write
 #pragma unroll
-    for (int q = 0; q < PER; ++q) stage_store<LOG2N, COLS, LOG2P, NSUB>(data, tid + LANES * q, v[q]);
-    __syncthreads();
-    wg_fft_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P), NSUB>(data, tw, tid);
+    for (int q = 0; q < PER; ++q) {
+      if constexpr (kLast) stage_store<LOG2N, COLS, LOG2P, NSUB>(last, tid + LANES * q, v[q]);
+      else stage_store<LOG2N, COLS, LOG2P, NSUB>(tile, tid + LANES * q, v[q]);
+    }
+    if constexpr (out_lds) __syncthreads();
+    wg_fft_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P), NSUB>(data, tw, tid, first, last);
   }
 }
 
-// NSUB transforms of length 2^LOG2N (default 4096 points), in place in LDS; the caller has already
-// synchronised after filling `data` and `tw`, and the result is visible to all lanes on return.
-template <int LOG2N, bool COLS, bool INV, int NSUB = (kPoints >> LOG2N)>
-__device__ __forceinline__ void wg_fft(cd* data, const cd* tw, int tid) {
-  wg_fft_from<LOG2N, COLS, INV, 0, NSUB>(data, tw, tid);
+// NSUB transforms of length 2^LOG2N through the LDS tile `data`.  `first(t, e)` feeds the first stage and
+// `last(t, e, value)` receives the last stage's outputs; either may be an LdsTile (kLds = true) or touch
+// global memory (kLds = false).  Contract: if `first` reads LDS the caller has synchronised after filling
+// it; if `last` writes LDS the result is visible to all lanes on return; if `last` does not, the tile may
+// still be read by other lanes on return - synchronise before overwriting it.  `tw` (stage-major table in
+// LDS) must be visible before the call whenever the transform has more than one stage.
+template <int LOG2N, bool COLS, bool INV, int NSUB, class FirstIn, class LastOut>
+__device__ __forceinline__ void wg_fft(cd* data, const cd* tw, int tid, const FirstIn& first, const LastOut& last) {
+  wg_fft_from<LOG2N, COLS, INV, 0, NSUB>(data, tw, tid, first, last);
 }
 #endif
 

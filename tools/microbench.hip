@@ -1,5 +1,5 @@
 // Ablation timings of the row pass (k_rows<10, conv>) on the metric geometry: G transforms of M = 196608 points.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I pyaudiolocalization_amd/csrc -I include tools/microbench.hip -o /tmp/microbench
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I pyaudiolocalization_amd/csrc -I include tools/microbench.hip -o tools/microbench
 // Variants: full | memory only (no FFT stages) | LDS/VALU only (no global traffic).
 #include <hip/hip_runtime.h>
 
@@ -10,10 +10,37 @@
 
 using namespace pal;
 
+template <int L2> struct GlobalIO {
+  static constexpr bool kLds = false;
+  cd* base;
+  __device__ cd operator()(int t, int e) const { return base[(t << L2) + e]; }
+  __device__ void operator()(int t, int e, cd v) const { base[(t << L2) + e] = v; }
+};
+template <int L2> struct ChatToLds {
+  static constexpr bool kLds = true;
+  cd* data;
+  const cd* ch;
+  __device__ void operator()(int t, int e, cd v) const { data[lds_addr<L2, false>(t, e)] = cmul(v, ch[(t << L2) + e]); }
+};
+template <int L2> struct ConstIn {
+  static constexpr bool kLds = false;
+  __device__ cd operator()(int t, int e) const { return mk(double(e), double(t)); }
+};
+template <int L2> struct ConstChatToLds {
+  static constexpr bool kLds = true;
+  cd* data;
+  __device__ void operator()(int t, int e, cd v) const { data[lds_addr<L2, false>(t, e)] = cmul(v, mk(0.5, 0.25)); }
+};
+template <int L2> struct Sink {
+  static constexpr bool kLds = false;
+  cd* base;
+  __device__ void operator()(int t, int e, cd v) const { if (v.x == 123.456) base[0] = v; }
+};
+
 template <int L2, int MODE>   // MODE 0 full, 1 memory only, 2 compute only
 __global__ __launch_bounds__(256) void rows(cd* __restrict__ W, const cd* __restrict__ chat, size_t m, int G,
                                             const cd* __restrict__ tws) {
-  constexpr int N2 = 1 << L2;
+  constexpr int N2 = 1 << L2, T = kPoints / N2;
   __shared__ cd data[kPoints];
   __shared__ cd tw[N2];
   const int tid = threadIdx.x;
@@ -21,30 +48,16 @@ __global__ __launch_bounds__(256) void rows(cd* __restrict__ W, const cd* __rest
   const size_t tile = blockIdx.x / G;
   for (int i = tid; i < stage_tw_size(L2); i += kLanes) tw[i] = tws[i];
   cd* base = W + size_t(g) * m + tile * kPoints;
-#pragma unroll
-  for (int q = 0; q < kPoints / kLanes; ++q) {
-    const int idx = tid + kLanes * q;
-    data[lds_addr<L2, false>(idx >> L2, idx & (N2 - 1))] = MODE == 2 ? mk(double(idx), 1.0) : base[idx];
-  }
-  __syncthreads();
-  if (MODE != 1) wg_fft<L2, false, false>(data, tw, tid);
   const cd* ch = chat + tile * kPoints;
+  if (MODE == 0) {
+    wg_fft<L2, false, false, T>(data, tw, tid, GlobalIO<L2>{base}, ChatToLds<L2>{data, ch});
+    wg_fft<L2, false, true, T>(data, tw, tid, LdsTile<L2, false, T>{data}, GlobalIO<L2>{base});
+  } else if (MODE == 1) {
 #pragma unroll
-  for (int q = 0; q < kPoints / kLanes; ++q) {
-    const int idx = tid + kLanes * q;
-    const int a = lds_addr<L2, false>(idx >> L2, idx & (N2 - 1));
-    data[a] = cmul(data[a], MODE == 2 ? mk(0.5, 0.25) : ch[idx]);
-  }
-  __syncthreads();
-  if (MODE != 1) wg_fft<L2, false, true>(data, tw, tid);
-  if (MODE == 2) {
-    if (data[tid].x == 123.456) base[0] = data[tid];      // keep the work alive, never true in practice
-    return;
-  }
-#pragma unroll
-  for (int q = 0; q < kPoints / kLanes; ++q) {
-    const int idx = tid + kLanes * q;
-    base[idx] = data[lds_addr<L2, false>(idx >> L2, idx & (N2 - 1))];
+    for (int q = 0; q < 16; ++q) { const int idx = tid + 256 * q; base[idx] = cmul(base[idx], ch[idx]); }
+  } else {
+    wg_fft<L2, false, false, T>(data, tw, tid, ConstIn<L2>{}, ConstChatToLds<L2>{data});
+    wg_fft<L2, false, true, T>(data, tw, tid, LdsTile<L2, false, T>{data}, Sink<L2>{base});
   }
 }
 
