@@ -50,15 +50,15 @@ struct Engine {
   hipStream_t stream = nullptr;    // FFT passes, copies, everything a caller can order against
   hipStream_t stream2 = nullptr;   // peak selection of launch group g while the passes of g+1 run on `stream`
   hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams
-  bool overlap = false;            // PAL_OVERLAP=1: alternate launch groups between the two streams (no gain measured)
+  bool overlap = true;             // alternate launch groups between the two streams (PAL_OVERLAP=0 turns it off)
   bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
   std::string err;
   int chunk = 128;                              // transforms per launch group (256 PHAT rows per peak-kernel launch: one per CU)
   std::map<std::tuple<int, int, int>, Plan> plans;   // (n, lin, nout) -> plan
   cd* stage_tw[12] = {};                        // stage-major twiddles per log2 N
   // growable device scratch
-  void* ws[8] = {};
-  size_t ws_bytes[8] = {};
+  void* ws[12] = {};
+  size_t ws_bytes[12] = {};
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;

@@ -29,14 +29,16 @@ int Engine::check(hipError_t e, const char* what) {
 
 int Engine::scratch(int idx, size_t bytes, void** out) {
   if (ws_bytes[idx] < bytes) {
-    if (ws[idx]) {
+    if (ws[idx]) {                       // either stream may still be using the old block
       PAL_HIP(hipStreamSynchronize(stream));
+      PAL_HIP(hipStreamSynchronize(stream2));
       PAL_HIP(hipFree(ws[idx]));
       ws[idx] = nullptr;
       ws_bytes[idx] = 0;
     }
     PAL_HIP(hipMalloc(&ws[idx], bytes));
     PAL_HIP(hipMemsetAsync(ws[idx], 0, bytes, stream));
+    PAL_HIP(hipStreamSynchronize(stream));   // the block may first be used on the other stream: zeroes must have landed
     ws_bytes[idx] = bytes;
   }
   *out = ws[idx];

@@ -49,6 +49,17 @@ struct PeakArgs {
   int n, n2;
   double fs, mult, med;   // med: NaN = no window
   int method, dist, num_peaks, snr_w;   // method: 0 median, 1 adaptive, < 0 metrics only
+  int splits;                            // workgroups per row (the last one to arrive finishes the row)
+  struct Partial* parts;                 // [rows][splits]
+  double* glist;                         // [rows][kList] bracket values of split rows
+  int* gcount;                           // [rows] fill of glist
+  int* arrive;                           // [rows] arrival tickets
+};
+
+struct Partial {                         // one workgroup's share of the streaming pass
+  double vmax, vmin, hb, s1, s2, a1, a2;
+  long long below;
+  int imax, imin, mb, pad;
 };
 
 struct Shared {
@@ -395,7 +406,8 @@ __device__ __forceinline__ void peak_test(Stream& t, const double* c, int n, int
 __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table, int32_t* ksel_multi, int* status) {
   __shared__ Shared s;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int row = blockIdx.x;
+  const int S = a.splits;
+  const int row = blockIdx.x / S, seg = blockIdx.x % S;
   const double* c = a.corr + size_t(row) * a.stride;
   const int n = a.n;
   const bool want_median = a.method == 0;
@@ -455,7 +467,12 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
   const bool aligned = (reinterpret_cast<size_t>(c) & 15) == 0;
   const int npair = (n + 1) / 2;
   constexpr int kTile = kT * kUnroll;                          // element pairs per tile
-  const int full = ((n / 2) / kTile) * kTile;                  // pairs covered by tiles in which every lane is valid
+  // this workgroup's share: a whole number of tiles, so segment borders fall on multiples of 128 elements
+  const int tiles_per_seg = ((npair + kTile - 1) / kTile + S - 1) / S;
+  const int p_lo = seg * tiles_per_seg * kTile < npair ? seg * tiles_per_seg * kTile : npair;
+  const int p_hi = p_lo + tiles_per_seg * kTile < npair ? p_lo + tiles_per_seg * kTile : npair;
+  const int both = p_hi < n / 2 ? p_hi : n / 2;                // pairs below `both` have two valid elements
+  const int full = p_lo + (both > p_lo ? (both - p_lo) / kTile * kTile : 0);   // end of the branch-free tiles
   // Element e = 2p (+1) of pair p; lane = p % 64.  Neighbours come from the adjacent lanes; the first element
   // of lane 0 and the second of lane 63 (e % 128 == 0 / 127) are peak-tested by the edge pass below instead.
   auto consume = [&](double xa, double xb, int e0, bool va, bool vb) {
@@ -477,7 +494,7 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
     }
   };
   if (aligned) {
-    for (int base = 0; base < full; base += kTile) {
+    for (int base = p_lo; base < full; base += kTile) {
       double2 v[kUnroll];
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) v[k] = *reinterpret_cast<const double2*>(c + 2 * (base + k * kT + tid));
@@ -485,7 +502,7 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
       for (int k = 0; k < kUnroll; ++k) consume(v[k].x, v[k].y, 2 * (base + k * kT + tid), true, true);
     }
   } else {
-    for (int base = 0; base < full; base += kTile) {
+    for (int base = p_lo; base < full; base += kTile) {
       double xa[kUnroll], xb[kUnroll];
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) {
@@ -496,25 +513,79 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
       for (int k = 0; k < kUnroll; ++k) consume(xa[k], xb[k], 2 * (base + k * kT + tid), true, true);
     }
   }
-  for (int p0 = full; p0 < npair; p0 += kT) {                  // tail: fewer than one tile of pairs
+  for (int p0 = full; p0 < p_hi; p0 += kT) {                   // tail: fewer than one tile of pairs
     const int e0 = 2 * (p0 + tid);
     const bool va = e0 < n, vb = e0 + 1 < n;
     const double xa = va ? c[e0] : 0.0, xb = vb ? c[e0 + 1] : 0.0;
     consume(xa, xb, e0, va, vb);
   }
-  for (int j = tid; 64 * j < n; j += kT) {                     // edge pass: e = 128 q and e = 128 q + 127
-    const int e = (j >> 1) * 128 + ((j & 1) ? 127 : 0);
-    if (e >= 1 && e <= n - 2) peak_test(t, c, n, e, c[e - 1], c[e], c[e + 1]);
+  for (int j = tid; 2 * p_lo + 64 * j < 2 * p_hi; j += kT) {   // edge pass: e = 128 q and e = 128 q + 127
+    const int e = 2 * p_lo + (j >> 1) * 128 + ((j & 1) ? 127 : 0);
+    if (e >= 1 && e <= n - 2 && e < 2 * p_hi) peak_test(t, c, n, e, c[e - 1], c[e], c[e + 1]);
   }
   double vmax = t.vmax, vmin = t.vmin, hb = t.hb;
   int imax = t.imax, imin = t.imin, mb = t.mb;
   barg<0>(vmax, imax, s, tid);
   barg<1>(vmin, imin, s, tid);
   barg<2>(hb, mb, s, tid);
-  const double s1 = bsum(t.s1, s, tid), s2 = bsum(t.s2, s, tid);
-  const double a1 = bsum(t.a1, s, tid), a2 = bsum(t.a2, s, tid);
+  double s1 = bsum(t.s1, s, tid), s2 = bsum(t.s2, s, tid);
+  double a1 = bsum(t.a1, s, tid), a2 = bsum(t.a2, s, tid);
+  long long below = want_median ? bsum_ll(t.below, s, tid) : 0;
+  int cnt = s.count;
+
+  if (S > 1) {
+    // ---- hand-off: every share publishes its partial result and bracket values; the last workgroup to arrive
+    //      (agent-scope release / acquire around one atomic ticket, cdna_hip_programming.md guideline 16) finishes the row
+    if (want_median) {
+      if (tid == 0) s.bc_i[3] = atomicAdd(&a.gcount[row], cnt);
+      __syncthreads();
+      const int at = s.bc_i[3];
+      double* dst = a.glist + size_t(row) * kList;
+      if (cnt <= kList && at >= 0)
+        for (int k = tid; k < cnt; k += kT)
+          if (at + k < kList) dst[at + k] = s.list[k];
+    }
+    if (tid == 0) {
+      Partial pt;
+      pt.vmax = vmax; pt.vmin = vmin; pt.hb = hb; pt.s1 = s1; pt.s2 = s2; pt.a1 = a1; pt.a2 = a2;
+      pt.below = below; pt.imax = imax; pt.imin = imin; pt.mb = mb; pt.pad = 0;
+      a.parts[size_t(row) * S + seg] = pt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s.bc_i[3] = atomicAdd(&a.arrive[row], 1);
+    }
+    __syncthreads();
+    if (s.bc_i[3] != S - 1) return;                            // workgroup-uniform: not the last share
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    imax = imin = mb = -1;
+    vmax = vmin = hb = s1 = s2 = a1 = a2 = 0;
+    below = 0;
+    for (int q = 0; q < S; ++q) {
+      const Partial pt = a.parts[size_t(row) * S + q];
+      if (pt.imax >= 0 && (imax < 0 || arg_better<0>(pt.vmax, pt.imax, vmax, imax))) { vmax = pt.vmax; imax = pt.imax; }
+      if (pt.imin >= 0 && (imin < 0 || arg_better<1>(pt.vmin, pt.imin, vmin, imin))) { vmin = pt.vmin; imin = pt.imin; }
+      if (pt.mb >= 0 && (mb < 0 || higher(pt.hb, pt.mb, hb, mb))) { hb = pt.hb; mb = pt.mb; }
+      s1 += pt.s1; s2 += pt.s2; a1 += pt.a1; a2 += pt.a2;
+      below += pt.below;
+    }
+    if (want_median) {
+      cnt = a.gcount[row];
+      const double* src = a.glist + size_t(row) * kList;
+      for (int k = tid; k < cnt && k < kList; k += kT) s.list[k] = src[k];
+    }
+    __syncthreads();
+  }
   const double mean_abs = ka + a1 / double(n);                 // np.mean(np.abs(corr)) (utils.py:155)
-  if (imax < 0) imax = 0;                                      // all-NaN row
+  if (imax < 0 || imax >= n) imax = 0;                         // all-NaN row (and a guard for every index used below)
+  if (mb >= n) mb = -1;
 
   // ---- SNR (utils.py:238-250): totals minus the window around the maximum ----
   const int wlo_s = imax - a.snr_w > 0 ? imax - a.snr_w : 0;
@@ -560,8 +631,6 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
   // ---- primary threshold (utils.py:144-149) ----
   double thr1;
   if (want_median) {
-    const long long below = bsum_ll(t.below, s, tid);
-    const int cnt = s.count;
     double m0 = 0, m1 = 0;
     bool ok = cnt <= kList && (long long)r1 >= below && (long long)r2 < below + cnt;
     if (ok) ok = list_select(s, tid, cnt, unsigned(r1 - below), lo, hi, m0);
@@ -654,8 +723,27 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
   a.method = prm.threshold_method; a.dist = prm.peak_distance; a.num_peaks = prm.num_peaks;
   const int w = int(0.01 * double(n));                       // utils.py:244
   a.snr_w = w > 1 ? w : 1;
+  // few rows: split each over several workgroups so that the launch covers the chip (one 157 KB-LDS workgroup per CU)
+  int splits = 256 / rows;
+  splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
+  a.splits = splits;
+  a.parts = nullptr; a.glist = nullptr; a.gcount = nullptr; a.arrive = nullptr;
+  if (splits > 1) {
+    const size_t per_slot = size_t(rows) * (2 * sizeof(int) + size_t(splits) * sizeof(Partial) + size_t(kList) * sizeof(double)) + 256;
+    void* sp = nullptr;
+    PAL_TRY(scratch(on == stream2 ? 9 : 8, per_slot, &sp));
+    char* base = static_cast<char*>(sp);
+    // tickets and list fills are zeroed by a memset node in front of every launch (the layout moves with `rows`)
+    PAL_HIP(hipMemsetAsync(base, 0, size_t(2 * rows) * sizeof(int), on));
+    a.arrive = reinterpret_cast<int*>(base);
+    a.gcount = a.arrive + rows;
+    size_t off = (size_t(2 * rows) * sizeof(int) + 127) & ~size_t(127);
+    a.parts = reinterpret_cast<Partial*>(base + off);
+    off = (off + size_t(rows) * splits * sizeof(Partial) + 127) & ~size_t(127);
+    a.glist = reinterpret_cast<double*>(base + off);
+  }
   ProfScope ps(this, metrics_only ? "k_peaks(metrics)" : "k_peaks", on);
-  k_peaks<<<dim3(rows), dim3(kT), 0, on>>>(a, table, ksel_multi, status);
+  k_peaks<<<dim3(rows * splits), dim3(kT), 0, on>>>(a, table, ksel_multi, status);
   return check(hipGetLastError(), "k_peaks");
 }
 
