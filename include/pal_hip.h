@@ -96,6 +96,12 @@ int pal_gcc_phat_all_pairs(pal_handle h, const double* frames, int B, int M, int
 int pal_gcc_phat_all_pairs_dev(pal_handle h, const double* d_frames, int B, int M, int L, const pal_phat_params* prm,
                                pal_pair_record* d_table);
 
+/* explicit pair list over rows[R][L]: pairs[P][2] row indices -> table[P].  Carries the 1000 shuffled
+ * correlations per pair of bootstrap_significance (utils.py:183-216) as one call (rows = sig1 + shuffles of sig2,
+ * pairs = (0, k)); only cmax of each record is used there. */
+int pal_gcc_phat_pairs(pal_handle h, const double* rows, int R, int L, const int32_t* pairs, int64_t P,
+                       const pal_phat_params* prm, pal_pair_record* table);
+
 /* single-pair signatures: phat_correlation(sig1, sig2) (utils.py:108) -> corr[n1+n2-1] */
 int pal_phat_correlation(pal_handle h, const double* sig1, int n1, const double* sig2, int n2, double* corr);
 /* get_time_delays_phat (utils.py:121): corr[n1+n2-1] (may be NULL), k_out[num_peaks] array indices */

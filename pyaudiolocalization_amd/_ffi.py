@@ -55,6 +55,7 @@ SIGNATURES = {
     "pal_gcc_phat_all_pairs": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(PhatParams), C.c_void_p,
                                          C.c_void_p]),
     "pal_gcc_phat_all_pairs_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(PhatParams), C.c_void_p]),
+    "pal_gcc_phat_pairs": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(PhatParams), C.c_void_p]),
     "pal_phat_correlation": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pal_get_time_delays_phat": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(PhatParams), C.c_void_p,
                                            C.c_void_p, C.c_void_p]),

@@ -159,6 +159,36 @@ static int all_pairs_dev(Engine* e, const double* d_frames, int B, int M, int L,
   return e->pair_correlations(*pl, spectra, static_cast<const int4*>(qp), np, L, *prm, d_table, nullptr, d_corr);
 }
 
+// explicit pair list over R equal-length rows (host buffers): one-vs-many bootstrap batches, sparse pair sets
+static int pairs_host(Engine* e, const double* rows_in, int R, int L, const int32_t* pairs, int64_t P,
+                      const pal_phat_params* prm, pal_pair_record* table) {
+  PAL_TRY(validate(e, prm));
+  if (!rows_in || !pairs || !table) return e->fail(PAL_ERR_INVALID, "NULL buffer");
+  if (R < 1 || L < 1 || P < 1) return e->fail(PAL_ERR_INVALID, "need R >= 1, L >= 1, P >= 1");
+  if (L > (1 << 20)) return e->fail(PAL_ERR_UNSUPPORTED, "frame length %d exceeds 2^20", L);
+  std::vector<int4> quads(size_t((P + 1) / 2), make_int4(0, 0, -1, -1));
+  for (int64_t k = 0; k < P; ++k) {
+    const int a = pairs[2 * k], b = pairs[2 * k + 1];
+    if (a < 0 || a >= R || b < 0 || b >= R) return e->fail(PAL_ERR_INVALID, "pair %lld references row outside 0..%d", (long long)k, R - 1);
+    int4& t = quads[size_t(k / 2)];
+    if (k & 1) { t.z = a; t.w = b; } else { t.x = a; t.y = b; }
+  }
+  Plan* pl = nullptr;
+  PAL_TRY(e->get_plan(2 * L - 1, L, 2 * L - 1, &pl));
+  void *df = nullptr, *sp = nullptr, *dt = nullptr, *dq = nullptr;
+  PAL_TRY(e->scratch(4, size_t(R) * L * sizeof(double), &df));
+  PAL_TRY(e->scratch(2, size_t(R) * pl->H * sizeof(cd), &sp));
+  PAL_TRY(e->scratch(5, size_t(P) * sizeof(pal_pair_record), &dt));
+  PAL_TRY(e->scratch(3, quads.size() * sizeof(int4), &dq));
+  PAL_TRY(e->check(hipMemcpyAsync(df, rows_in, size_t(R) * L * sizeof(double), hipMemcpyHostToDevice, e->stream), "rows upload"));
+  PAL_TRY(e->check(hipMemcpyAsync(dq, quads.data(), quads.size() * sizeof(int4), hipMemcpyHostToDevice, e->stream), "pairs upload"));
+  PAL_TRY(e->check(hipStreamSynchronize(e->stream), "upload sync"));
+  PAL_TRY(e->forward_spectra(*pl, static_cast<const double*>(df), size_t(L), R, L, static_cast<cd*>(sp)));
+  PAL_TRY(e->pair_correlations(*pl, static_cast<const cd*>(sp), static_cast<const int4*>(dq), P, L, *prm,
+                               static_cast<pal_pair_record*>(dt), nullptr, nullptr));
+  return e->check(hipMemcpyAsync(table, dt, size_t(P) * sizeof(pal_pair_record), hipMemcpyDeviceToHost, e->stream), "table download");
+}
+
 }  // namespace pal
 
 using namespace pal;
@@ -291,6 +321,13 @@ int pal_gcc_phat_all_pairs(pal_handle h, const double* frames, int B, int M, int
                         static_cast<double*>(dc)));
   PAL_TRY(e->check(hipMemcpyAsync(table, dt, size_t(np) * sizeof(pal_pair_record), hipMemcpyDeviceToHost, e->stream), "table download"));
   if (corr) PAL_TRY(e->check(hipMemcpyAsync(corr, dc, size_t(np) * size_t(2 * L - 1) * sizeof(double), hipMemcpyDeviceToHost, e->stream), "corr download"));
+  return pal_synchronize(h);
+}
+
+int pal_gcc_phat_pairs(pal_handle h, const double* rows, int R, int L, const int32_t* pairs, int64_t P,
+                       const pal_phat_params* prm, pal_pair_record* table) {
+  ENGINE(h);
+  PAL_TRY(pairs_host(e, rows, R, L, pairs, P, prm, table));
   return pal_synchronize(h);
 }
 

@@ -134,6 +134,19 @@ class Engine:
         self._check(self._lib.pal_gcc_phat_all_pairs_dev(self._h, C.c_void_p(d_frames), b, m, length, C.byref(prm),
                                                          C.c_void_p(d_table)))
 
+    def gcc_phat_pairs(self, rows, pairs, fs, threshold_method="median", threshold_multiplier=1.0,
+                       max_expected_delay=None) -> np.ndarray:
+        """rows[R][L] and an explicit pair list pairs[P][2] (row indices) -> table[P]."""
+        x = f64(rows)
+        if x.ndim != 2:
+            raise ValueError("rows must be [R][L]")
+        pr = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        table = np.zeros(pr.shape[0], dtype=RECORD)
+        prm = make_params(fs, 1, threshold_method, threshold_multiplier, max_expected_delay)
+        self._check(self._lib.pal_gcc_phat_pairs(self._h, x.ctypes.data, x.shape[0], x.shape[1], pr.ctypes.data, pr.shape[0],
+                                                 C.byref(prm), table.ctypes.data))
+        return table
+
     def phat_correlation(self, sig1, sig2) -> np.ndarray:
         a, b = f64(sig1), f64(sig2)
         if a.ndim != 1 or b.ndim != 1:

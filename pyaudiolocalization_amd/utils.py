@@ -120,25 +120,34 @@ def compute_snr(corr: np.ndarray) -> float:
 
 # ---------------------------------------------------------------- significance (next row N1)
 def bootstrap_significance(sig1: np.ndarray, sig2: np.ndarray, fs: float, num_bootstrap: int = 1000, alpha: float = 0.05,
-                           bootstrap_mode: str = "permutation", block_size: int = 50) -> float:
-    """(1 - alpha) percentile of max(PHAT(sig1, shuffled sig2)) (utils.py:183-216); the PHAT maxima
-    come from the engine, the shuffles from the global NumPy RNG like the reference."""
+                           bootstrap_mode: str = "permutation", block_size: int = 50, batch: int = 250) -> float:
+    """(1 - alpha) percentile of max(PHAT(sig1, shuffled sig2)) (utils.py:183-216).  The shuffles come from
+    the global NumPy RNG like the reference (so the result is statistically, not bitwise, comparable); the
+    PHAT correlations of a batch of shuffles run as ONE one-vs-many engine call."""
+    if bootstrap_mode not in ("permutation", "block", "circular"):
+        raise ValueError("unknown bootstrap_mode; use 'permutation', 'block' or 'circular'")
+    a, b = np.asarray(sig1, dtype=np.float64), np.asarray(sig2, dtype=np.float64)
+    if a.shape != b.shape:            # unequal lengths: fall back to one engine call per shuffle
+        batch = 1
     eng = default_engine()
-    sig2 = np.asarray(sig2)
-    peaks = []
-    for _ in range(num_bootstrap):
-        if bootstrap_mode == "permutation":
-            other = np.random.permutation(sig2)
-        elif bootstrap_mode == "block":
-            blocks = [sig2[i:i + block_size] for i in range(0, len(sig2), block_size)]
-            np.random.shuffle(blocks)
-            other = np.concatenate(blocks)[: len(sig2)]
-        elif bootstrap_mode == "circular":
-            other = np.roll(sig2, np.random.randint(0, len(sig2)))
+    peaks: List[float] = []
+    while len(peaks) < num_bootstrap:
+        count = min(batch, num_bootstrap - len(peaks))
+        rows = [a]
+        for _ in range(count):
+            if bootstrap_mode == "permutation":
+                rows.append(np.random.permutation(b))
+            elif bootstrap_mode == "block":
+                blocks = [b[i:i + block_size] for i in range(0, len(b), block_size)]
+                np.random.shuffle(blocks)
+                rows.append(np.concatenate(blocks)[: len(b)])
+            else:
+                rows.append(np.roll(b, np.random.randint(0, len(b))))
+        if a.shape == b.shape:
+            pairs = np.stack([np.zeros(count, dtype=np.int32), np.arange(1, count + 1, dtype=np.int32)], axis=1)
+            peaks.extend(eng.gcc_phat_pairs(np.array(rows), pairs, fs)["cmax"].tolist())
         else:
-            raise ValueError("unknown bootstrap_mode; use 'permutation', 'block' or 'circular'")
-        _, rec, _ = eng.get_time_delays_phat(sig1, other, fs, want_corr=False)
-        peaks.append(rec["cmax"])
+            peaks.append(float(eng.get_time_delays_phat(a, rows[1], fs, want_corr=False)[1]["cmax"]))
     return np.percentile(peaks, 100 * (1 - alpha))
 
 

@@ -122,6 +122,44 @@ def test_all_pairs_small_batches(engine):
                     p += 1
 
 
+def test_pair_list_and_bootstrap(engine):
+    """Explicit pair lists (pal_gcc_phat_pairs) and the one-vs-many bootstrap built on them (utils.py:183-216)."""
+    from pyaudiolocalization_amd import pair_list
+    from pyaudiolocalization_amd import utils as U
+    rng = np.random.default_rng(17)
+    rows = rng.standard_normal((7, 1800))
+    rows[1:] += 0.6 * rows[:1]
+    full = engine.gcc_phat_all_pairs(rows, 16000.0, max_expected_delay=0.004)
+    pick = np.array([0, 5, 6, 11, 20, 3, 3])
+    sub = engine.gcc_phat_pairs(rows, pair_list(7)[pick], 16000.0, max_expected_delay=0.004)
+    for key in ("k_sel", "branch", "k_argmax"):
+        assert np.array_equal(sub[key], full[key][pick]), key
+    assert np.allclose(sub["cmax"], full["cmax"][pick], rtol=1e-12)
+    with pytest.raises(ValueError):
+        engine.gcc_phat_pairs(rows, [[0, 7]], 16000.0)
+    a, b = rows[0], rows[1]
+    for mode in ("permutation", "block", "circular"):
+        np.random.seed(5)
+        got = U.bootstrap_significance(a, b, 16000.0, num_bootstrap=40, bootstrap_mode=mode, batch=16)
+        np.random.seed(5)
+        peaks = []
+        for _ in range(40):                      # the reference's loop, with the oracle's PHAT
+            if mode == "permutation":
+                other = np.random.permutation(b)
+            elif mode == "block":
+                blocks = [b[i:i + 50] for i in range(0, len(b), 50)]
+                np.random.shuffle(blocks)
+                other = np.concatenate(blocks)[: len(b)]
+            else:
+                other = np.roll(b, np.random.randint(0, len(b)))
+            peaks.append(np.max(O.phat_correlation(a, other)))
+        assert np.isclose(got, np.percentile(peaks, 95), rtol=1e-12), mode
+    with pytest.raises(ValueError):
+        U.bootstrap_significance(a, b, 16000.0, bootstrap_mode="nope")
+    m = U.compute_cross_correlation_metrics(O.phat_correlation(a, b), a, b, 16000.0)
+    assert set(m) == {"peak_to_peak_ratio", "snr", "significant"} and bool(m["significant"]) is True
+
+
 def test_chunk_size_does_not_change_results(engine):
     frames = np.random.default_rng(4).standard_normal((2, 6, 1500))
     engine.set_chunk(32)
