@@ -121,9 +121,11 @@ struct PairLoader {
     const bool mirror = j >= (unsigned)H;
     const unsigned jj = mirror ? n - j : j;
     const int4 q = quad[g];
-    cd r1 = whiten(S[size_t(q.x) * H + jj], S[size_t(q.y) * H + jj]);
+    const cd sa = S[size_t(q.x) * H + jj];
+    cd r1 = whiten(sa, S[size_t(q.y) * H + jj]);
     cd r2 = mk(0, 0);
-    if (q.z >= 0) r2 = whiten(S[size_t(q.z) * H + jj], S[size_t(q.w) * H + jj]);
+    // consecutive pairs of the i<j order share their first mic: reuse its spectrum bin (a quarter of the reads)
+    if (q.z >= 0) r2 = whiten(q.z == q.x ? sa : S[size_t(q.z) * H + jj], S[size_t(q.w) * H + jj]);
     if (mirror) { r1.y = -r1.y; r2.y = -r2.y; }
     return cmul(mk(r1.x - r2.y, r1.y + r2.x), w[j]);
   }
