@@ -72,7 +72,8 @@ def main() -> None:
         dist_mod.init_process_group("gloo", rank=rank, world_size=world)
         dist = dist_mod
 
-    eng = Engine(local_rank)
+    # one process per GPU; PAL_BENCH_SHARE_GPU=1 lets a rehearsal on a one-GPU box put every rank on device 0
+    eng = Engine(0 if os.environ.get("PAL_BENCH_SHARE_GPU") == "1" else local_rank)
     if args.chunk > 0:
         eng.set_chunk(args.chunk)
     b, m, length = args.frames, args.mics, args.length
