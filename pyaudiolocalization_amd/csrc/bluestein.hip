@@ -103,9 +103,20 @@ struct SpectrumStorer {
 };
 
 // R = S_a conj(S_b);  R /= |R| + 1e-10        (utils.py:116-117)
+// The magnitude and the reciprocal use the hardware estimates (v_rsq_f64 / v_rcp_f64) plus two Newton steps
+// each (relative error ~1e-16) instead of the IEEE-exact sqrt and divide sequences: a third of the loader's
+// instructions, and the result only has to be right to the rounding level of the transforms around it.
 __device__ __forceinline__ cd whiten(cd a, cd b) {
   const cd r = cmulc(a, b);
-  const double inv = 1.0 / (sqrt(r.x * r.x + r.y * r.y) + 1e-10);
+  const double m2 = __builtin_fma(r.x, r.x, r.y * r.y);
+  double y = __builtin_amdgcn_rsq(m2);
+  y = y * __builtin_fma(-0.5 * m2 * y, y, 1.5);
+  y = y * __builtin_fma(-0.5 * m2 * y, y, 1.5);
+  const double mag = m2 > 0 ? m2 * y : 0.0;               // |R| (rsq(0) is infinite)
+  const double d = mag + 1e-10;
+  double inv = __builtin_amdgcn_rcp(d);
+  inv = inv * __builtin_fma(-d, inv, 2.0);
+  inv = inv * __builtin_fma(-d, inv, 2.0);
   return mk(r.x * inv, r.y * inv);
 }
 

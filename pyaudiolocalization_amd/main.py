@@ -99,6 +99,36 @@ def _warn_branches(table) -> None:
             log.warning("%s for %d microphone pair(s)", text, hit)
 
 
+def solve_position(mic_positions, mic_pairs, td_diffs, c, weights=None, clustering_method="kmeans", clustering_eps=0.001,
+                   clustering_min_samples=2) -> np.ndarray:
+    """TDOA table -> source position exactly as main.py:233-298: clustered start points, extended bounds,
+    bounded trust-region least squares from every start (best successful cost wins), differential
+    evolution when none succeeds, first start as the last resort.  Host side (3 unknowns, SciPy / scikit-learn
+    like the reference); kept separate so that it can be pinned against the reference's fixtures without a GPU."""
+    from scipy.optimize import differential_evolution, least_squares
+    if weights is None:
+        weights = np.ones(len(mic_pairs))
+    guesses = heuristic_initialization_adaptive(mic_positions, mic_pairs, td_diffs, c, clustering_method=clustering_method,
+                                                eps=clustering_eps, min_samples=clustering_min_samples)
+    bounds = dynamic_bounds_extended(mic_positions, td_diffs, c, buffer=5.0)
+    lower = [b[0] for b in bounds]
+    upper = [b[1] for b in bounds]
+    guesses = [np.array([np.clip(g[k], lower[k], upper[k]) for k in range(len(g))]) for g in guesses]
+    best = None
+    for guess in guesses:
+        fit = least_squares(equations, guess, args=(mic_positions, mic_pairs, td_diffs, c, weights), bounds=(lower, upper),
+                            method="trf", ftol=1e-6, xtol=1e-6, gtol=1e-6)
+        if fit.success and (best is None or fit.cost < best.cost):
+            best = fit
+    if best is not None:
+        return np.array(best.x)
+    log.warning("least squares failed for every start, trying differential evolution")
+    de = differential_evolution(lambda v: np.sum(np.square(equations(v, mic_positions, mic_pairs, td_diffs, c, weights))),
+                                bounds=list(zip(lower, upper)), strategy="best1bin", maxiter=1000, popsize=15, tol=1e-6,
+                                mutation=(0.5, 1), recombination=0.7, polish=True, init="latinhypercube")
+    return np.array(de.x) if de.success else np.array(guesses[0])
+
+
 def localize_sound_source(config, calibration_data=None, audio_files=None, use_simulation=True, show_plots=True):
     fs = config["fs"]
     duration = config["duration"]
@@ -180,29 +210,10 @@ def localize_sound_source(config, calibration_data=None, audio_files=None, use_s
         corr_matrix[i, j] = corr_matrix[j, i] = row["cmax"]                   # main.py:223-225
 
     # ---- host tail: main.py:233-298 ---------------------------------------------------------------
-    from scipy.optimize import differential_evolution, least_squares
-    guesses = heuristic_initialization_adaptive(mic_positions, mic_pairs, td_diffs, c, clustering_method=clustering_method,
-                                                eps=clustering_eps, min_samples=clustering_min_samples)
-    bounds = dynamic_bounds_extended(mic_positions, td_diffs, c, buffer=5.0)
-    lower = [b[0] for b in bounds]
-    upper = [b[1] for b in bounds]
-    guesses = [np.array([np.clip(g[k], lower[k], upper[k]) for k in range(len(g))]) for g in guesses]
     weights = compute_weights(correlation_metrics, mic_pairs) if analyze_correlation and correlation_metrics \
         else np.ones(len(mic_pairs))
-    best = None
-    for guess in guesses:
-        fit = least_squares(equations, guess, args=(mic_positions, mic_pairs, td_diffs, c, weights), bounds=(lower, upper),
-                            method="trf", ftol=1e-6, xtol=1e-6, gtol=1e-6)
-        if fit.success and (best is None or fit.cost < best.cost):
-            best = fit
-    if best is not None:
-        position = np.array(best.x)
-    else:
-        log.warning("least squares failed for every start, trying differential evolution")
-        de = differential_evolution(lambda v: np.sum(np.square(equations(v, mic_positions, mic_pairs, td_diffs, c, weights))),
-                                    bounds=list(zip(lower, upper)), strategy="best1bin", maxiter=1000, popsize=15, tol=1e-6,
-                                    mutation=(0.5, 1), recombination=0.7, polish=True, init="latinhypercube")
-        position = np.array(de.x) if de.success else np.array(guesses[0])
+    position = solve_position(mic_positions, mic_pairs, td_diffs, c, weights, clustering_method, clustering_eps,
+                              clustering_min_samples)
     log.info("estimated source: (%.3f, %.3f, %.3f) m", *position)
 
     # ---- plots: main.py:300-319 (files are written when show_plots is False) ------------

@@ -241,17 +241,17 @@ def dynamic_bounds_extended(mic_positions, tdoas, c, buffer: float = 5.0) -> Lis
 
 
 def equations(vars, mic_positions, mic_pairs, tdoas, c, weights: Optional[np.ndarray] = None) -> List[float]:
-    """Weighted range-difference residuals (d_j - d_i) - c td (utils.py:384-405)."""
+    """Weighted range-difference residuals (d_j - d_i) - c td (utils.py:384-405), evaluated for all pairs at
+    once (the reference loops in Python: 12.5 ms per call at 2016 pairs)."""
     if weights is not None and len(weights) != len(mic_pairs):
         raise ValueError("length of weights must equal the number of mic pairs")
-    src = np.array(vars)
-    out = []
-    for k, ((i, j), td) in enumerate(zip(mic_pairs, tdoas)):
-        r = (np.linalg.norm(src - np.array(mic_positions[j])) - np.linalg.norm(src - np.array(mic_positions[i]))) - c * td
-        if weights is not None:
-            r *= weights[k]
-        out.append(r)
-    return out
+    mics = np.asarray(mic_positions, dtype=np.float64)
+    pairs = np.asarray(mic_pairs, dtype=np.int64).reshape(-1, 2)
+    ranges = np.sqrt(np.sum((np.asarray(vars, dtype=np.float64) - mics) ** 2, axis=1))
+    res = (ranges[pairs[:, 1]] - ranges[pairs[:, 0]]) - c * np.asarray(tdoas, dtype=np.float64)[: pairs.shape[0]]
+    if weights is not None:
+        res = res * np.asarray(weights)
+    return list(res)
 
 
 def compute_weights(correlation_metrics, mic_pairs) -> np.ndarray:
