@@ -54,6 +54,7 @@ struct PeakArgs {
   double* glist;                         // [rows][kList] bracket values of split rows
   int* gcount;                           // [rows] fill of glist
   int* arrive;                           // [rows] arrival tickets
+  unsigned long long* stamps;            // diagnostics only (PAL_PEAK_STAMPS=1): [rows][8] 100 MHz clock reads of lane 0
 };
 
 struct Partial {                         // one workgroup's share of the streaming pass
@@ -67,6 +68,7 @@ struct Shared {
   unsigned hist[kBins];
   double small[kSmall];
   double red_d[kNW];
+  double many[kNW * 8];
   int red_i[kNW];
   long long red_l[kNW];
   unsigned wave_tot[kNW];
@@ -87,6 +89,23 @@ __device__ __forceinline__ bool higher(double h1, int m1, double h2, int m2) {  
 }
 
 __device__ double bsum(double v, Shared& s, int tid) { return block_sum<kNW>(v, s.red_d, tid); }
+template <int N> __device__ void bsum_many(double (&v)[N], Shared& s, int tid) {   // N sums, one barrier pair
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_down(v[q], o, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) s.many[(tid >> 6) * N + q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    double r = 0;
+    for (int k = 0; k < kNW; ++k) r += s.many[k * N + q];
+    v[q] = r;
+  }
+}
 __device__ long long bsum_ll(long long v, Shared& s, int tid) { return block_sum_ll<kNW>(v, s.red_l, tid); }
 template <int MODE> __device__ void barg(double& v, int& i, Shared& s, int tid) {
   block_arg<MODE, kNW>(v, i, s.red_d, s.red_i, tid);
@@ -143,7 +162,7 @@ __device__ __forceinline__ void append(bool pred, double v, double* list, int* c
 }
 
 // ---- scipy _local_maxima_1d, evaluated for one sample ----
-__device__ bool peak_mid(const double* c, int n, int m, double& h) {
+__device__ __forceinline__ bool peak_mid(const double* c, int n, int m, double& h) {
   if (m < 1 || m > n - 2) return false;
   const double x = c[m];
   int l = m, r = m;
@@ -208,7 +227,7 @@ __device__ __forceinline__ int digit_shift(int level) { return level < 5 ? 52 - 
 __device__ __forceinline__ unsigned digit_mask(int level) { return level < 5 ? 0x7FFu : 0xFFu; }
 __device__ __forceinline__ unsigned long long mag_key(double x) { return (unsigned long long)__double_as_longlong(fabs(x)); }
 
-__device__ double radix_select(const double* c, int n, int tid, Shared& s, unsigned rank) {
+__device__ __forceinline__ double radix_select(const double* c, int n, int tid, Shared& s, unsigned rank) {
   unsigned long long prefix = 0;
   unsigned inner = rank, bin, pop;
   for (int level = 0; level < 6; ++level) {
@@ -265,7 +284,7 @@ __device__ int memo_find(const Shared& s, int pos) {
 }
 
 // returns 1 kept, 0 suppressed, -1 overflow; workgroup-uniform control flow
-__device__ int resolve(const double* c, int n, int dist, int tid, Shared& s, int pos0, double h0) {
+__device__ __forceinline__ int resolve(const double* c, int n, int dist, int tid, Shared& s, int pos0, double h0) {
   if (tid == 0) { s.stack_n = 1; s.stack_pos[0] = pos0; s.stack_h[0] = h0; s.flag = 0; }
   __syncthreads();
   for (int guard = 0; guard < 100000; ++guard) {
@@ -327,7 +346,12 @@ __device__ __forceinline__ bool in_window(int m, int n2, double fs, double med) 
 
 // highest-priority peak with height >= thr inside [wlo, whi] (exact window test when windowed) and
 // priority below (bound_h, bound_m); returns false when none
-__device__ bool next_candidate(const PeakArgs& a, const double* c, int tid, Shared& s, double thr, bool windowed, int wlo,
+struct SelArgs {            // by value: a reference to the kernel's argument struct would force it (and the address
+  int n, n2, dist, num_peaks;   // space of every pointer in it) through private memory
+  double fs, med;
+};
+
+__device__ __forceinline__ bool next_candidate(const SelArgs a, const double* c, int tid, Shared& s, double thr, bool windowed, int wlo,
                                int whi, double bound_h, int bound_m, double& ch, int& cm) {
   double bh = 0;
   int bm = -1;
@@ -346,7 +370,7 @@ __device__ bool next_candidate(const PeakArgs& a, const double* c, int tid, Shar
 }
 
 // top-num_peaks kept peaks >= thr in the window; returns count or -1 on overflow
-__device__ int select_peaks(const PeakArgs& a, const double* c, int tid, Shared& s, double thr, bool windowed, int wlo,
+__device__ __forceinline__ int select_peaks(const SelArgs a, const double* c, int tid, Shared& s, double thr, bool windowed, int wlo,
                             int whi, double first_h, int first_m, int* sel, double* selh) {
   if (tid == 0) s.memo_n = 0;
   __syncthreads();
@@ -375,12 +399,34 @@ struct Stream {            // per-lane accumulators of the single pass over the 
   double vmax, vmin, hb;
   int imax, imin, mb;
   double s1, s2, a1, a2;   // sums of (x-K0), (x-K0)^2, (|x|-Ka), (|x|-Ka)^2
-  long long below;
+  int below;
+  // Wavefront-uniform filters: the best maximum / minimum / peak height any lane of this wavefront has seen up to
+  // the previous tile.  Almost every sample fails all three compares and skips the bookkeeping; the filters are
+  // refreshed (three butterfly reductions) only after a tile in which some lane recorded something.
+  double bmax, bmin, bhb;
+  int dirty;
 };
 
+__device__ __forceinline__ double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ void refresh_filters(Stream& t) {
+  if (__ballot(t.dirty != 0) == 0) return;
+  t.bmax = wave_max(t.imax >= 0 ? t.vmax : -INFINITY);
+  t.bmin = -wave_max(t.imin >= 0 ? -t.vmin : -INFINITY);
+  t.bhb = wave_max(t.mb >= 0 ? t.hb : -INFINITY);
+  t.dirty = 0;
+}
+
 __device__ __forceinline__ void visit(Stream& t, double x, int i, double k0, double ka) {
-  if (t.imax < 0 || x > t.vmax) { t.vmax = x; t.imax = i; }
-  if (t.imin < 0 || x < t.vmin) { t.vmin = x; t.imin = i; }
+  if (x > t.bmax) {                                     // first occurrence wins: strict compare inside the lane
+    if (t.imax < 0 || x > t.vmax) { t.vmax = x; t.imax = i; t.dirty = 1; }
+  }
+  if (x < t.bmin) {
+    if (t.imin < 0 || x < t.vmin) { t.vmin = x; t.imin = i; t.dirty = 1; }
+  }
   const double d = x - k0, e = fabs(x) - ka;
   t.s1 += d;
   t.s2 += d * d;
@@ -390,7 +436,7 @@ __device__ __forceinline__ void visit(Stream& t, double x, int i, double k0, dou
 
 // x at index i with neighbours l (i-1) and r (i+1): record it when it is a local maximum (plateaus: slow path)
 __device__ __forceinline__ void peak_test(Stream& t, const double* c, int n, int i, double l, double x, double r) {
-  if (i < 1 || i > n - 2 || !(l < x)) return;
+  if (!(x >= t.bhb) || i < 1 || i > n - 2 || !(l < x)) return;   // only a peak at least as high as the best so far matters
   int m = i;
   if (r == x) {                                    // plateau that starts here: find its right edge in memory
     int q = i + 1;
@@ -400,7 +446,7 @@ __device__ __forceinline__ void peak_test(Stream& t, const double* c, int n, int
   } else if (!(r < x)) {
     return;
   }
-  if (t.mb < 0 || higher(x, m, t.hb, t.mb)) { t.hb = x; t.mb = m; }
+  if (t.mb < 0 || higher(x, m, t.hb, t.mb)) { t.hb = x; t.mb = m; t.dirty = 1; }
 }
 
 __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table, int32_t* ksel_multi, int* status) {
@@ -411,6 +457,13 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
   const double* c = a.corr + size_t(row) * a.stride;
   const int n = a.n;
   const bool want_median = a.method == 0;
+  int stamp_at = 0;
+  unsigned long long* const stamps = a.stamps;   // (a local: capturing the argument struct by reference would push it,
+  auto stamp = [&]() {                           //  and every pointer in it, through private memory)
+    if (stamps && tid == 0 && stamp_at < 8) stamps[size_t(blockIdx.x) * 8 + stamp_at] = __builtin_amdgcn_s_memrealtime();
+    ++stamp_at;   // never set in production runs; values go to a buffer nothing else reads
+  };
+  stamp();
 
   // ---- block sample (16 coalesced runs of kT samples spread over the row): shifts for the one-pass
   //      variances and the pivots that bracket the median ----
@@ -457,6 +510,7 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
   }
   if (tid == 0) s.count = 0;
   __syncthreads();
+  stamp();
 
   // ---- the single pass: branch-free tiles of kUnroll 16-byte loads per lane, then a short guarded tail ----
   Stream t;
@@ -464,6 +518,9 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
   t.imax = t.imin = t.mb = -1;
   t.s1 = t.s2 = t.a1 = t.a2 = 0;
   t.below = 0;
+  t.bmax = t.bhb = -INFINITY;
+  t.bmin = INFINITY;
+  t.dirty = 0;
   const bool aligned = (reinterpret_cast<size_t>(c) & 15) == 0;
   const int npair = (n + 1) / 2;
   constexpr int kTile = kT * kUnroll;                          // element pairs per tile
@@ -475,31 +532,67 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
   const int full = p_lo + (both > p_lo ? (both - p_lo) / kTile * kTile : 0);   // end of the branch-free tiles
   // Element e = 2p (+1) of pair p; lane = p % 64.  Neighbours come from the adjacent lanes; the first element
   // of lane 0 and the second of lane 63 (e % 128 == 0 / 127) are peak-tested by the edge pass below instead.
-  auto consume = [&](double xa, double xb, int e0, bool va, bool vb) {
-    const double left = __shfl_up(xb, 1, 64);
-    const double right = __shfl_down(xa, 1, 64);
-    if (va) {
-      visit(t, xa, e0, k0, ka);
-      if (lane != 0) peak_test(t, c, n, e0, left, xa, xb);
+  // One tile = kUnroll element pairs per lane.  Statistics and peak tests per element; the bracket values of the
+  // whole tile are appended with ONE LDS atomic per wavefront: per element a ballot gives the lane's rank
+  // (mbcnt) and the wavefront's count (scalar popcount), the running scalar total is the tile's reservation.
+  auto consume_tile = [&](const double* xa, const double* xb, int pair0, bool full_tile) {
+    int off[2 * kUnroll];
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const int e0 = 2 * (pair0 + k * kT);
+      const bool va = full_tile || e0 < n, vb = full_tile || e0 + 1 < n;
+      const double left = __shfl_up(xb[k], 1, 64);
+      const double right = __shfl_down(xa[k], 1, 64);
+      if (va) {
+        visit(t, xa[k], e0, k0, ka);
+        if (lane != 0) peak_test(t, c, n, e0, left, xa[k], xb[k]);
+      }
+      if (vb) {
+        visit(t, xb[k], e0 + 1, k0, ka);
+        if (lane != 63) peak_test(t, c, n, e0 + 1, xa[k], xb[k], right);
+      }
+      if (want_median) {
+        const double ma = fabs(xa[k]), mb_ = fabs(xb[k]);
+        t.below += int(va && ma < lo) + int(vb && mb_ < lo);
+        const bool ha = va && ma >= lo && ma <= hi, hb_ = vb && mb_ >= lo && mb_ <= hi;
+        const unsigned long long m0 = __ballot(ha), m1 = __ballot(hb_);
+        off[2 * k] = ha ? run + int(__builtin_amdgcn_mbcnt_hi(unsigned(m0 >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m0), 0u))) : -1;
+        run += __popcll(m0);
+        off[2 * k + 1] = hb_ ? run + int(__builtin_amdgcn_mbcnt_hi(unsigned(m1 >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m1), 0u))) : -1;
+        run += __popcll(m1);
+      }
     }
-    if (vb) {
-      visit(t, xb, e0 + 1, k0, ka);
-      if (lane != 63) peak_test(t, c, n, e0 + 1, xa, xb, right);
+    if (want_median && run > 0) {                              // wavefront-uniform
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s.count, run);
+      base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+      for (int k = 0; k < kUnroll; ++k) {
+        if (off[2 * k] >= 0 && base + off[2 * k] < kList) s.list[base + off[2 * k]] = fabs(xa[k]);
+        if (off[2 * k + 1] >= 0 && base + off[2 * k + 1] < kList) s.list[base + off[2 * k + 1]] = fabs(xb[k]);
+      }
     }
-    if (want_median) {
-      const double ma = fabs(xa), mb_ = fabs(xb);
-      t.below += (va && ma < lo) + (vb && mb_ < lo);
-      append(va && ma >= lo && ma <= hi, ma, s.list, &s.count, kList, lane);
-      append(vb && mb_ >= lo && mb_ <= hi, mb_, s.list, &s.count, kList, lane);
-    }
+    refresh_filters(t);
   };
+  // register double buffer: the next tile's loads are in flight while this one is consumed (one 157 KB-LDS
+  // workgroup per CU leaves only 8 wavefronts to hide the latency, so the loop must do it itself)
   if (aligned) {
+    double2 cur[kUnroll], nxt[kUnroll];
+    if (p_lo < full) {
+#pragma unroll
+      for (int k = 0; k < kUnroll; ++k) cur[k] = *reinterpret_cast<const double2*>(c + 2 * (p_lo + k * kT + tid));
+    }
     for (int base = p_lo; base < full; base += kTile) {
-      double2 v[kUnroll];
+      const int ahead = base + kTile < full ? base + kTile : base;    // last round re-reads its own tile: no branch
 #pragma unroll
-      for (int k = 0; k < kUnroll; ++k) v[k] = *reinterpret_cast<const double2*>(c + 2 * (base + k * kT + tid));
+      for (int k = 0; k < kUnroll; ++k) nxt[k] = *reinterpret_cast<const double2*>(c + 2 * (ahead + k * kT + tid));
+      double xa[kUnroll], xb[kUnroll];
 #pragma unroll
-      for (int k = 0; k < kUnroll; ++k) consume(v[k].x, v[k].y, 2 * (base + k * kT + tid), true, true);
+      for (int k = 0; k < kUnroll; ++k) { xa[k] = cur[k].x; xb[k] = cur[k].y; }
+      consume_tile(xa, xb, base + tid, true);
+#pragma unroll
+      for (int k = 0; k < kUnroll; ++k) cur[k] = nxt[k];
     }
   } else {
     for (int base = p_lo; base < full; base += kTile) {
@@ -509,28 +602,33 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
         xa[k] = c[2 * (base + k * kT + tid)];
         xb[k] = c[2 * (base + k * kT + tid) + 1];
       }
-#pragma unroll
-      for (int k = 0; k < kUnroll; ++k) consume(xa[k], xb[k], 2 * (base + k * kT + tid), true, true);
+      consume_tile(xa, xb, base + tid, true);
     }
   }
-  for (int p0 = full; p0 < p_hi; p0 += kT) {                   // tail: fewer than one tile of pairs
-    const int e0 = 2 * (p0 + tid);
-    const bool va = e0 < n, vb = e0 + 1 < n;
-    const double xa = va ? c[e0] : 0.0, xb = vb ? c[e0 + 1] : 0.0;
-    consume(xa, xb, e0, va, vb);
+  if (full < p_hi) {                                           // tail: one guarded tile
+    double xa[kUnroll], xb[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const int e0 = 2 * (full + k * kT + tid);
+      xa[k] = e0 < n ? c[e0] : 0.0;
+      xb[k] = e0 + 1 < n ? c[e0 + 1] : 0.0;
+    }
+    consume_tile(xa, xb, full + tid, false);
   }
   for (int j = tid; 2 * p_lo + 64 * j < 2 * p_hi; j += kT) {   // edge pass: e = 128 q and e = 128 q + 127
     const int e = 2 * p_lo + (j >> 1) * 128 + ((j & 1) ? 127 : 0);
     if (e >= 1 && e <= n - 2 && e < 2 * p_hi) peak_test(t, c, n, e, c[e - 1], c[e], c[e + 1]);
   }
+  stamp();
   double vmax = t.vmax, vmin = t.vmin, hb = t.hb;
   int imax = t.imax, imin = t.imin, mb = t.mb;
   barg<0>(vmax, imax, s, tid);
   barg<1>(vmin, imin, s, tid);
   barg<2>(hb, mb, s, tid);
-  double s1 = bsum(t.s1, s, tid), s2 = bsum(t.s2, s, tid);
-  double a1 = bsum(t.a1, s, tid), a2 = bsum(t.a2, s, tid);
-  long long below = want_median ? bsum_ll(t.below, s, tid) : 0;
+  double sums[5] = {t.s1, t.s2, t.a1, t.a2, double(t.below)};   // one barrier pair for all five (counts < 2^31 are exact in fp64)
+  bsum_many<5>(sums, s, tid);
+  double s1 = sums[0], s2 = sums[1], a1 = sums[2], a2 = sums[3];
+  long long below = (long long)sums[4];
   int cnt = s.count;
 
   if (S > 1) {
@@ -587,6 +685,7 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
   if (imax < 0 || imax >= n) imax = 0;                         // all-NaN row (and a guard for every index used below)
   if (mb >= n) mb = -1;
 
+  stamp();
   // ---- SNR (utils.py:238-250): totals minus the window around the maximum ----
   const int wlo_s = imax - a.snr_w > 0 ? imax - a.snr_w : 0;
   const int whi_s = imax + a.snr_w < n ? imax + a.snr_w : n;
@@ -628,6 +727,7 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
     return;
   }
 
+  stamp();
   // ---- primary threshold (utils.py:144-149) ----
   double thr1;
   if (want_median) {
@@ -646,6 +746,7 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
     thr1 = a.mult * (mean_abs + sqrt(va));                     // mean + std of |corr| (utils.py:147)
   }
 
+  stamp();
   // ---- fallback chain (utils.py:152-179) ----
   int branch = 0;
   int sel[PAL_MAX_PEAKS];
@@ -670,16 +771,18 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
   }
   if (!argmax_fallback) {
     const bool first_ok = !windowed;                       // unwindowed: the best peak is already known
-    count = select_peaks(a, c, tid, s, thr, windowed, wlo, whi, first_ok ? hb : 0.0, first_ok ? mb : -1, sel, selh);
+    const SelArgs sa{n, a.n2, a.dist, a.num_peaks, a.fs, a.med};
+    count = select_peaks(sa, c, tid, s, thr, windowed, wlo, whi, first_ok ? hb : 0.0, first_ok ? mb : -1, sel, selh);
     if (count < 0) overflow = true;
     if (count == 0 && windowed) {
       branch |= PAL_BR_WINDOW_RETRY;
-      count = select_peaks(a, c, tid, s, mean_abs, true, wlo, whi, 0.0, -1, sel, selh);
+      count = select_peaks(sa, c, tid, s, mean_abs, true, wlo, whi, 0.0, -1, sel, selh);
       if (count < 0) overflow = true;
       if (count == 0) { branch |= PAL_BR_ARGMAX_WINDOW; argmax_fallback = true; }
     }
   }
   if (argmax_fallback || overflow) { sel[0] = imax; selh[0] = vmax; count = 1; }
+  stamp();
 
   if (tid == 0) {
     pal_pair_record r;
@@ -728,6 +831,12 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
   splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
   a.splits = splits;
   a.parts = nullptr; a.glist = nullptr; a.gcount = nullptr; a.arrive = nullptr;
+  a.stamps = nullptr;
+  if (getenv("PAL_PEAK_STAMPS")) {               // diagnostic runs only: phase clocks of every workgroup of this launch
+    void* st = nullptr;
+    PAL_TRY(scratch(10, size_t(8192) * 8 * sizeof(unsigned long long), &st));
+    a.stamps = static_cast<unsigned long long*>(st);
+  }
   if (splits > 1) {
     const size_t per_slot = size_t(rows) * (2 * sizeof(int) + size_t(splits) * sizeof(Partial) + size_t(kList) * sizeof(double)) + 256;
     void* sp = nullptr;
