@@ -161,6 +161,11 @@ int pal_profile_entry(pal_handle h, int index, char* name, int cap, double* tota
 /* transform geometry of the all-pairs plan for frames of L samples: n = 2L-1, conv length M, M1, M2 */
 int pal_plan_info(pal_handle h, int L, int32_t* n, int32_t* conv_len, int32_t* m1, int32_t* m2);
 
+/* Prime-factor route of the inverse transform for frame length L: n = n1 * n2 (coprime, odd) with the n2-point
+ * DFTs as in-LDS chirp convolutions of `tile_len` points.  All three are 0 when n has no such split (or
+ * PAL_PFA=0) and the four-step chirp convolution reported by pal_plan_info does the inverse too. */
+int pal_plan_factors(pal_handle h, int L, int32_t* n1, int32_t* n2, int32_t* tile_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,7 @@ SIGNATURES = {
     "pal_profile_get": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pal_profile_entry": (C.c_int, [_H, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pal_plan_info": (C.c_int, [_H, C.c_int, _PI, _PI, _PI, _PI]),
+    "pal_plan_factors": (C.c_int, [_H, C.c_int, _PI, _PI, _PI]),
 }
 
 _lib: Optional[C.CDLL] = None

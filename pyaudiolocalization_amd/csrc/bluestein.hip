@@ -25,10 +25,12 @@
 namespace pal {
 
 // ------------------------------------------------------------------ table generators
-__global__ void k_make_chirp(cd* w, int n) {
+// w[j] = exp(i pi mult j^2 / n)
+__global__ void k_make_chirp(cd* w, int n, int mult) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   unsigned long long r = (unsigned long long)j * (unsigned long long)j % (2ull * (unsigned long long)n);
+  r = r * (unsigned long long)mult % (2ull * (unsigned long long)n);
   double sgn = 1.0;
   if (r >= (unsigned long long)n) { r -= n; sgn = -1.0; }
   double s, c;
@@ -45,11 +47,18 @@ __global__ void k_make_roots(cd* out, int count, double denom) {
   out[q] = mk(c, s);
 }
 
-__global__ void k_make_stage_tw(cd* out, int ln) {
+__global__ void k_make_stage_tw(cd* out, int ln, bool compact) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   for (int lp = stage_log2r(ln, 0); lp < ln; lp += stage_log2r(ln, lp)) {
     const int R = stage_radix(ln, lp), P = 1 << lp, off = stage_tw_offset(ln, lp);
-    if (idx >= off && idx < off + (R - 1) * P) {
+    if (compact && stage_is_last(ln, lp)) {          // rows r = 1, 2, 4 (, 8) only
+      if (idx >= off && idx < off + stage_log2r(ln, lp) * P) {
+        const int r = 1 << ((idx - off) / P), k = (idx - off) % P;
+        double s, c;
+        sincospi(-2.0 * double(k * r) / double(P * R), &s, &c);
+        out[idx] = mk(c, s);
+      }
+    } else if (idx >= off && idx < off + (R - 1) * P) {
       const int r = (idx - off) / P + 1, k = (idx - off) % P;
       double s, c;
       sincospi(-2.0 * double(k * r) / double(P * R), &s, &c);
@@ -102,24 +111,6 @@ struct SpectrumStorer {
   }
 };
 
-// R = S_a conj(S_b);  R /= |R| + 1e-10        (utils.py:116-117)
-// The magnitude and the reciprocal use the hardware estimates (v_rsq_f64 / v_rcp_f64) plus two Newton steps
-// each (relative error ~1e-16) instead of the IEEE-exact sqrt and divide sequences: a third of the loader's
-// instructions, and the result only has to be right to the rounding level of the transforms around it.
-__device__ __forceinline__ cd whiten(cd a, cd b) {
-  const cd r = cmulc(a, b);
-  const double m2 = __builtin_fma(r.x, r.x, r.y * r.y);
-  double y = __builtin_amdgcn_rsq(m2);
-  y = y * __builtin_fma(-0.5 * m2 * y, y, 1.5);
-  y = y * __builtin_fma(-0.5 * m2 * y, y, 1.5);
-  const double mag = m2 > 0 ? m2 * y : 0.0;               // |R| (rsq(0) is infinite)
-  const double d = mag + 1e-10;
-  double inv = __builtin_amdgcn_rcp(d);
-  inv = inv * __builtin_fma(-d, inv, 2.0);
-  inv = inv * __builtin_fma(-d, inv, 2.0);
-  return mk(r.x * inv, r.y * inv);
-}
-
 // inverse transform input: (R^p_k + i R^q_k) w_k over the full Hermitian-extended grid k < n
 struct PairLoader {
   static constexpr const char* kName = "PairLoader";
@@ -163,10 +154,21 @@ const cd* Engine::stage_table(int ln) {
     cd* p = nullptr;
     if (hipMalloc(&p, sizeof(cd) << ln) != hipSuccess) return nullptr;
     (void)hipMemsetAsync(p, 0, sizeof(cd) << ln, stream);
-    k_make_stage_tw<<<dim3(((1 << ln) + 255) / 256), dim3(256), 0, stream>>>(p, ln);
+    k_make_stage_tw<<<dim3(((1 << ln) + 255) / 256), dim3(256), 0, stream>>>(p, ln, false);
     stage_tw[ln] = p;
   }
   return stage_tw[ln];
+}
+
+const cd* Engine::stage_table_compact(int ln) {
+  if (!stage_twc[ln]) {
+    cd* p = nullptr;
+    if (hipMalloc(&p, sizeof(cd) << ln) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(p, 0, sizeof(cd) << ln, stream);
+    k_make_stage_tw<<<dim3(((1 << ln) + 255) / 256), dim3(256), 0, stream>>>(p, ln, true);
+    stage_twc[ln] = p;
+  }
+  return stage_twc[ln];
 }
 
 // Convolution geometry for at least `needed` points: the smaller of 2^k and 3 * 2^k (k >= 12 for the latter, so
@@ -233,12 +235,13 @@ int Engine::get_plan(int n, int lin, int nout, Plan** out) {
   pl.lin = lin;
   pl.nout = nout;
   PAL_HIP(hipMalloc(&pl.w, size_t(n) * sizeof(cd)));
-  k_make_chirp<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(pl.w, n);
+  k_make_chirp<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(pl.w, n, 1);
   PAL_HIP(hipGetLastError());
   // forward: j < lin inputs, k < H outputs, kernel w_{k-j}
   PAL_TRY(build_conv(pl.fwd, pl.w, n, lin, pl.H, false, 1.0));
   // inverse: k < n inputs, m < nout outputs, kernel conj(w_{m-k}); 1/n of numpy.fft.ifft folded in
   PAL_TRY(build_conv(pl.inv, pl.w, n, n, nout, true, 1.0 / double(n)));
+  PAL_TRY(build_pfa(pl));                      // prime-factor route of the PHAT inverse, when n splits
   PAL_HIP(hipStreamSynchronize(stream));
   auto ins = plans.emplace(key, pl);
   *out = &ins.first->second;
@@ -264,17 +267,25 @@ int Engine::forward_spectra(Plan& pl, const double* frames, size_t frame_stride,
   return PAL_OK;
 }
 
-int Engine::pair_correlations(Plan& pl, const cd* spectra, const int4* quads, int64_t npairs, int n2,
+int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4* quads, int64_t npairs, int n2,
                               const pal_phat_params& prm, pal_pair_record* table, int32_t* ksel_multi,
                               double* corr_out) {
   Engine* e = this;
   const Conv& c = pl.inv;
   const int n = pl.n;
+  const bool pfa = pl.pfa.on();
+  const cd* permuted = nullptr;
+  if (pfa) {   // mic spectra in the (k mod N1, k mod N2) layout of pfa.hip, once per call
+    void* pp = nullptr;
+    PAL_TRY(scratch(11, size_t(nspec) * pl.pfa.rows() * pl.pfa.n2 * sizeof(cd), &pp));
+    PAL_TRY(pfa_permute(pl, spectra, nspec, static_cast<cd*>(pp), stream));
+    permuted = static_cast<const cd*>(pp);
+  }
   // Launch groups alternate between two HIP streams, each with its own workspace and correlation buffer: the
   // memory-bound head and tail of one group's kernels overlap the LDS/VALU-bound middle of the other's, and the
   // peak kernel of group g runs beside the FFT passes of group g+1.  Same-slot reuse is ordered by the stream.
   const bool two = overlap && table != nullptr;
-  const size_t wpoints = size_t(chunk) * c.M();
+  const size_t wpoints = size_t(chunk) * (pfa ? size_t(n) : c.M());
   void* wsp = nullptr;
   PAL_TRY(scratch(0, (two ? 2 : 1) * wpoints * sizeof(cd), &wsp));
   cd* W = static_cast<cd*>(wsp);
@@ -299,11 +310,15 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, const int4* quads, in
     // odd tail with a caller buffer: the imaginary half of the last transform has no destination row there
     const bool via_scratch = !corr_out || rows < 2 * G;
     double* crow = via_scratch ? cbuf + size_t(slot) * buf_doubles : corr_out + size_t(p0) * stride;
-    PairLoader ld{spectra, quads + t0, n, pl.H, pl.w};
-    CorrStorer st{crow, stride, n, pl.w};
-    PAL_TRY(launch_cols_fwd(e, c, G, ld, Wg, on));
-    PAL_TRY(launch_rows(e, c, G, Wg, true, 1.0, on));
-    PAL_TRY(launch_cols_inv(e, c, G, Wg, st, on));
+    if (pfa) {
+      PAL_TRY(pfa_pair_group(pl, permuted, quads + t0, G, Wg, crow, stride, on));
+    } else {
+      PairLoader ld{spectra, quads + t0, n, pl.H, pl.w};
+      CorrStorer st{crow, stride, n, pl.w};
+      PAL_TRY(launch_cols_fwd(e, c, G, ld, Wg, on));
+      PAL_TRY(launch_rows(e, c, G, Wg, true, 1.0, on));
+      PAL_TRY(launch_cols_inv(e, c, G, Wg, st, on));
+    }
     if (corr_out && via_scratch)
       PAL_HIP(hipMemcpyAsync(corr_out + size_t(p0) * stride, crow, size_t(rows) * stride * sizeof(double),
                              hipMemcpyDeviceToDevice, on));

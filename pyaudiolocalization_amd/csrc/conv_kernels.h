@@ -16,13 +16,31 @@
 
 namespace pal {
 
-__global__ void k_make_chirp(cd* w, int n);
+__global__ void k_make_chirp(cd* w, int n, int mult);
 __global__ void k_make_roots(cd* out, int count, double denom);
-__global__ void k_make_stage_tw(cd* out, int ln);
+__global__ void k_make_stage_tw(cd* out, int ln, bool compact);
 
 // exp(-2 pi i e / M) for e < M from the two root tables (e = q * M2 + r)
 __device__ __forceinline__ cd four_step_twiddle(unsigned e, int l2, const cd* __restrict__ twA, const cd* __restrict__ twB) {
   return cmul(twA[e >> l2], twB[e & ((1u << l2) - 1)]);
+}
+
+// R = S_a conj(S_b);  R /= |R| + 1e-10        (utils.py:116-117)
+// The magnitude and the reciprocal use the hardware estimates (v_rsq_f64 / v_rcp_f64) plus two Newton steps
+// each (relative error ~1e-16) instead of the IEEE-exact sqrt and divide sequences: a third of the loader's
+// instructions, and the result only has to be right to the rounding level of the transforms around it.
+__device__ __forceinline__ cd whiten(cd a, cd b) {
+  const cd r = cmulc(a, b);
+  const double m2 = __builtin_fma(r.x, r.x, r.y * r.y);
+  double y = __builtin_amdgcn_rsq(m2);
+  y = y * __builtin_fma(-0.5 * m2 * y, y, 1.5);
+  y = y * __builtin_fma(-0.5 * m2 * y, y, 1.5);
+  const double mag = m2 > 0 ? m2 * y : 0.0;               // |R| (rsq(0) is infinite)
+  const double d = mag + 1e-10;
+  double inv = __builtin_amdgcn_rcp(d);
+  inv = inv * __builtin_fma(-d, inv, 2.0);
+  inv = inv * __builtin_fma(-d, inv, 2.0);
+  return mk(r.x * inv, r.y * inv);
 }
 
 // ------------------------------------------------------------------ stage sources / sinks

@@ -29,6 +29,22 @@ struct Conv {
   int M2() const { return 1 << l2; }
 };
 
+// Prime-factor cut n = N1 x N2 (coprime, both odd) of the inverse PHAT transform (pfa.hip): N2-point DFTs as
+// chirp convolutions of length M = 2^lm that never leave LDS, then dense N1-point DFTs down the columns.
+struct Pfa {
+  int n1 = 0, n2 = 0;      // N1 <= 127 (dense), N2 <= M/2 (in-LDS Bluestein)
+  int lm = 0;              // log2 M, 10..12
+  int u1 = 0;              // N2^-1 mod N1
+  long long e1 = 0, e2 = 0;   // CRT idempotents: k = (e1 k1 + e2 k2) mod n
+  int nch = 1;             // accumulator chunks of the column pass
+  cd* b = nullptr;         // chirp exp(i pi u2 j^2 / N2), j < N2 (u2 = N1^-1 mod N2, made even)
+  cd* hhat = nullptr;      // FFT_M of the conjugate chirp kernel, scaled by 1 / (M n)
+  cd* r1 = nullptr;        // exp(-2 pi i q / N1), q < N1
+  double* T = nullptr;     // cos / sin (2 pi j t / N1) in the column pass's chunked order
+  int rows() const { return (n1 + 1) / 2; }   // spectrum rows k1 <= (N1-1)/2 kept by the permuted layout
+  bool on() const { return n1 > 0; }
+};
+
 // Exact-length-n DFT plan (Bluestein / chirp-z): forward real -> half spectrum, inverse pairs.
 struct Plan {
   int n = 0;        // DFT length
@@ -38,6 +54,7 @@ struct Plan {
   cd* w = nullptr;  // chirp exp(i pi j^2 / n), j < n
   Conv fwd;         // forward:  lin inputs -> H outputs
   Conv inv;         // inverse:  n inputs  -> n outputs (two real sequences per complex transform)
+  Pfa pfa;          // prime-factor route of the PHAT inverse when n splits (otherwise `inv` does it)
 };
 
 struct ProfileSlot {
@@ -52,13 +69,15 @@ struct Engine {
   hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams
   bool overlap = true;             // alternate launch groups between the two streams (PAL_OVERLAP=0 turns it off)
   bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
+  bool allow_pfa = true;           // PAL_PFA=0 keeps the PHAT inverse on the four-step chirp convolution
   std::string err;
   int chunk = 128;                              // transforms per launch group (256 PHAT rows per peak-kernel launch: one per CU)
   std::map<std::tuple<int, int, int>, Plan> plans;   // (n, lin, nout) -> plan
-  cd* stage_tw[12] = {};                        // stage-major twiddles per log2 N
+  cd* stage_tw[13] = {};                        // stage-major twiddles per log2 N
+  cd* stage_twc[13] = {};                       // the same with a compact last stage (fft_core.h stage_twc_size)
   // growable device scratch
-  void* ws[12] = {};
-  size_t ws_bytes[12] = {};
+  void* ws[16] = {};
+  size_t ws_bytes[16] = {};
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -77,6 +96,12 @@ struct Engine {
   int check(hipError_t e, const char* what);
   int scratch(int idx, size_t bytes, void** out);
   const cd* stage_table(int ln);
+  const cd* stage_table_compact(int ln);
+  int build_pfa(Plan& pl);                  // pfa.hip: choose the split and make the tables (leaves pl.pfa off if none fits)
+  void free_pfa(Pfa& f);
+  int pfa_permute(const Plan& pl, const cd* spectra, int nspec, cd* out, hipStream_t on);
+  int pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, double* corr, size_t stride,
+                     hipStream_t on);
   int get_plan(int n, int lin, int nout, Plan** out);
   int alloc_conv(Conv& c, size_t needed);   // geometry, tables and chirp-spectrum storage for >= `needed` points
   void free_conv(Conv& c);
@@ -89,7 +114,7 @@ struct Engine {
 
   // pipelines (all pointers are device pointers)
   int forward_spectra(Plan& pl, const double* frames, size_t frame_stride, int rows, int len, cd* spectra);
-  int pair_correlations(Plan& pl, const cd* spectra, const int4* quads, int64_t npairs, int n2,
+  int pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4* quads, int64_t npairs, int n2,
                         const pal_phat_params& prm, pal_pair_record* table, int32_t* ksel_multi, double* corr_out);
   int peaks(const double* corr, size_t stride, int rows, int n, int n2, const pal_phat_params& prm,
             pal_pair_record* table, int32_t* ksel_multi, hipStream_t on);

@@ -139,6 +139,18 @@ PAL_HD constexpr int stage_tw_offset(int ln, int lp) {
   return off;
 }
 PAL_HD constexpr int stage_tw_size(int ln) { return stage_tw_offset(ln, ln); }   // < 2^ln
+// Compact variant: the LAST stage (the one with the largest P) keeps only the rows r = 1, 2, 4 (, 8) at the same
+// offset - entries [b*P + k] = exp(-2 pi i k 2^b / (P R)) - and the other factors are products of those rows
+// (at most three multiplies deep).  A 2048-point transform then needs 1008 table entries instead of 2032, which
+// is what lets two 64 KB workgroups share a CU's LDS.
+PAL_HD constexpr int stage_tw_last(int ln) {
+  int lp = 0;
+  while (!stage_is_last(ln, lp)) lp += stage_log2r(ln, lp);
+  return lp;
+}
+PAL_HD constexpr int stage_twc_size(int ln) {
+  return stage_tw_offset(ln, stage_tw_last(ln)) + stage_log2r(ln, stage_tw_last(ln)) * (1 << stage_tw_last(ln));
+}
 
 // LDS address of element e of sub-transform t.
 //   COLS: t fastest (lanes of a wavefront walk the columns of a tile, no conflicts for >= 8 columns).
@@ -164,7 +176,7 @@ template <int LOG2N, bool COLS, int R, int NSUB = (kPoints >> LOG2N)> PAL_HD voi
 }
 
 // read the R inputs of work item w through `in(t, e)`, apply the stage twiddles, run the radix-R DFT
-template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB, class In>
+template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB, bool COMPACT = false, class In>
 PAL_HD void stage_load(const In& in, const cd* tw, int w, cd* v) {
   constexpr int R = stage_radix(LOG2N, LOG2P), N = 1 << LOG2N, P = 1 << LOG2P, NB = N / R;
   int i, t;
@@ -174,10 +186,23 @@ PAL_HD void stage_load(const In& in, const cd* tw, int w, cd* v) {
   if (P > 1) {
     const int k = i & (P - 1);
     const cd* tws = tw + stage_tw_offset(LOG2N, LOG2P);
+    if (COMPACT && stage_is_last(LOG2N, LOG2P)) {
+      cd f[R];
 #pragma unroll
-    for (int r = 1; r < R; ++r) {
-      cd f = tws[(r - 1) * P + k];
-      v[r] = INV ? cmulc(v[r], f) : cmul(v[r], f);
+      for (int b = 0; (1 << b) < R; ++b) f[1 << b] = tws[b * P + k];
+#pragma unroll
+      for (int r = 3; r < R; ++r) {
+        const int hi = r >= 8 ? 8 : (r >= 4 ? 4 : 2);
+        if (r != hi) f[r] = cmul(f[hi], f[r - hi]);
+      }
+#pragma unroll
+      for (int r = 1; r < R; ++r) v[r] = INV ? cmulc(v[r], f[r]) : cmul(v[r], f[r]);
+    } else {
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        cd f = tws[(r - 1) * P + k];
+        v[r] = INV ? cmulc(v[r], f) : cmul(v[r], f);
+      }
     }
   }
   dftR<R, INV>(v);
@@ -234,7 +259,7 @@ template <int LOG2N, int T> struct LdsTile3 {
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------- workgroup transform (device)
-template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB, class FirstIn, class LastOut>
+template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB, bool COMPACT, class FirstIn, class LastOut>
 __device__ __forceinline__ void wg_fft_from(cd* data, const cd* tw, int tid, const FirstIn& first, const LastOut& last) {
   if constexpr (LOG2P < LOG2N) {
     constexpr int R = stage_radix(LOG2N, LOG2P);
@@ -246,8 +271,8 @@ __device__ __forceinline__ void wg_fft_from(cd* data, const cd* tw, int tid, con
     cd v[PER][R];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-      if constexpr (kFirst) stage_load<LOG2N, COLS, INV, LOG2P, NSUB>(first, tw, tid + LANES * q, v[q]);
-      else stage_load<LOG2N, COLS, INV, LOG2P, NSUB>(tile, tw, tid + LANES * q, v[q]);
+      if constexpr (kFirst) stage_load<LOG2N, COLS, INV, LOG2P, NSUB, COMPACT>(first, tw, tid + LANES * q, v[q]);
+      else stage_load<LOG2N, COLS, INV, LOG2P, NSUB, COMPACT>(tile, tw, tid + LANES * q, v[q]);
     }
     if constexpr (in_lds && out_lds) __syncthreads();            // in place: every read before any write
 #pragma unroll
@@ -256,7 +281,7 @@ __device__ __forceinline__ void wg_fft_from(cd* data, const cd* tw, int tid, con
       else stage_store<LOG2N, COLS, LOG2P, NSUB>(tile, tid + LANES * q, v[q]);
     }
     if constexpr (out_lds) __syncthreads();
-    wg_fft_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P), NSUB>(data, tw, tid, first, last);
+    wg_fft_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P), NSUB, COMPACT>(data, tw, tid, first, last);
   }
 }
 
@@ -265,10 +290,11 @@ __device__ __forceinline__ void wg_fft_from(cd* data, const cd* tw, int tid, con
 // global memory (kLds = false).  Contract: if `first` reads LDS the caller has synchronised after filling
 // it; if `last` writes LDS the result is visible to all lanes on return; if `last` does not, the tile may
 // still be read by other lanes on return - synchronise before overwriting it.  `tw` (stage-major table in
-// LDS) must be visible before the call whenever the transform has more than one stage.
-template <int LOG2N, bool COLS, bool INV, int NSUB, class FirstIn, class LastOut>
+// LDS; the compact layout when COMPACT) must be visible before the call whenever the transform has more than
+// one stage.
+template <int LOG2N, bool COLS, bool INV, int NSUB, bool COMPACT = false, class FirstIn, class LastOut>
 __device__ __forceinline__ void wg_fft(cd* data, const cd* tw, int tid, const FirstIn& first, const LastOut& last) {
-  wg_fft_from<LOG2N, COLS, INV, 0, NSUB>(data, tw, tid, first, last);
+  wg_fft_from<LOG2N, COLS, INV, 0, NSUB, COMPACT>(data, tw, tid, first, last);
 }
 #endif
 

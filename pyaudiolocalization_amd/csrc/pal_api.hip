@@ -156,7 +156,7 @@ static int all_pairs_dev(Engine* e, const double* d_frames, int B, int M, int L,
   }
   void* qp = e->quads;
   const int64_t np = int64_t(B) * M * (M - 1) / 2;
-  return e->pair_correlations(*pl, spectra, static_cast<const int4*>(qp), np, L, *prm, d_table, nullptr, d_corr);
+  return e->pair_correlations(*pl, spectra, rows, static_cast<const int4*>(qp), np, L, *prm, d_table, nullptr, d_corr);
 }
 
 // explicit pair list over R equal-length rows (host buffers): one-vs-many bootstrap batches, sparse pair sets
@@ -184,7 +184,7 @@ static int pairs_host(Engine* e, const double* rows_in, int R, int L, const int3
   PAL_TRY(e->check(hipMemcpyAsync(dq, quads.data(), quads.size() * sizeof(int4), hipMemcpyHostToDevice, e->stream), "pairs upload"));
   PAL_TRY(e->check(hipStreamSynchronize(e->stream), "upload sync"));
   PAL_TRY(e->forward_spectra(*pl, static_cast<const double*>(df), size_t(L), R, L, static_cast<cd*>(sp)));
-  PAL_TRY(e->pair_correlations(*pl, static_cast<const cd*>(sp), static_cast<const int4*>(dq), P, L, *prm,
+  PAL_TRY(e->pair_correlations(*pl, static_cast<const cd*>(sp), R, static_cast<const int4*>(dq), P, L, *prm,
                                static_cast<pal_pair_record*>(dt), nullptr, nullptr));
   return e->check(hipMemcpyAsync(table, dt, size_t(P) * sizeof(pal_pair_record), hipMemcpyDeviceToHost, e->stream), "table download");
 }
@@ -225,6 +225,8 @@ int pal_create(int device, pal_handle* out) {
   if (env) e->overlap = atoi(env) != 0;
   env = getenv("PAL_RADIX3");
   if (env) e->allow_r3 = atoi(env) != 0;
+  env = getenv("PAL_PFA");
+  if (env) e->allow_pfa = atoi(env) != 0;
   *out = reinterpret_cast<pal_handle>(e);
   return PAL_OK;
 }
@@ -239,8 +241,10 @@ void pal_destroy(pal_handle h) {
     hipFree(kv.second.w);
     e->free_conv(kv.second.fwd);
     e->free_conv(kv.second.inv);
+    e->free_pfa(kv.second.pfa);
   }
   for (cd* p : e->stage_tw) if (p) hipFree(p);
+  for (cd* p : e->stage_twc) if (p) hipFree(p);
   for (void* p : e->ws) if (p) hipFree(p);
   if (e->quads) hipFree(e->quads);
   for (hipEvent_t ev : e->ev_pool) hipEventDestroy(ev);
@@ -356,7 +360,7 @@ static int single_pair(Engine* e, const double* sig1, int n1, const double* sig2
   PAL_TRY(e->forward_spectra(*pl, d, size_t(lin), 1, n1, S));
   PAL_TRY(e->forward_spectra(*pl, d + lin, size_t(lin), 1, n2, S + pl->H));
   pal_phat_params dummy{};
-  PAL_TRY(e->pair_correlations(*pl, S, static_cast<const int4*>(qp), 1, n2, prm ? *prm : dummy,
+  PAL_TRY(e->pair_correlations(*pl, S, 2, static_cast<const int4*>(qp), 1, n2, prm ? *prm : dummy,
                                prm ? static_cast<pal_pair_record*>(dt) : nullptr,
                                prm ? static_cast<int32_t*>(dk) : nullptr, static_cast<double*>(dc)));
   if (corr) PAL_TRY(e->check(hipMemcpyAsync(corr, dc, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, e->stream), "corr download"));
@@ -403,6 +407,17 @@ int pal_plan_info(pal_handle h, int L, int32_t* n, int32_t* conv_len, int32_t* m
   if (conv_len) *conv_len = int32_t(pl->inv.M());
   if (m1) *m1 = pl->inv.M1();
   if (m2) *m2 = pl->inv.M2();
+  return PAL_OK;
+}
+
+int pal_plan_factors(pal_handle h, int L, int32_t* n1, int32_t* n2, int32_t* tile_len) {
+  ENGINE(h);
+  if (L < 1 || L > (1 << 20)) return e->fail(PAL_ERR_INVALID, "bad frame length");
+  Plan* pl = nullptr;
+  PAL_TRY(e->get_plan(2 * L - 1, L, 2 * L - 1, &pl));
+  if (n1) *n1 = pl->pfa.n1;
+  if (n2) *n2 = pl->pfa.n2;
+  if (tile_len) *tile_len = pl->pfa.on() ? 1 << pl->pfa.lm : 0;
   return PAL_OK;
 }
 

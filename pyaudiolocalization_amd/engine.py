@@ -103,7 +103,10 @@ class Engine:
     def plan_info(self, frame_len: int) -> dict:
         v = [C.c_int32() for _ in range(4)]
         self._check(self._lib.pal_plan_info(self._h, int(frame_len), *[C.byref(x) for x in v]))
-        return {"n": v[0].value, "conv_len": v[1].value, "m1": v[2].value, "m2": v[3].value}
+        f = [C.c_int32() for _ in range(3)]
+        self._check(self._lib.pal_plan_factors(self._h, int(frame_len), *[C.byref(x) for x in f]))
+        return {"n": v[0].value, "conv_len": v[1].value, "m1": v[2].value, "m2": v[3].value,
+                "n1": f[0].value, "n2": f[1].value, "tile_len": f[2].value}
 
     # ---- hot path A --------------------------------------------------------------------
     def gcc_phat_all_pairs(self, frames, fs, num_peaks=1, threshold_method="median", threshold_multiplier=1.0,

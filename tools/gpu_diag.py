@@ -175,5 +175,28 @@ def stamps():
     os.environ.pop("PAL_PEAK_STAMPS")
 
 
+def pfa():
+    """Prime-factor route against the four-step route and the oracle, per length."""
+    os.environ["PAL_PFA"] = "0"
+    e4 = Engine(0)
+    os.environ["PAL_PFA"] = "1"
+    ep = Engine(0)
+    for L in (50, 500, 1000, 2048, 2999, 3000, 5000, 44100):
+        a, b = rng.standard_normal(L), rng.standard_normal(L)
+        info = ep.plan_info(L)
+        got = ep.phat_correlation(a, b)
+        ref = e4.phat_correlation(a, b)
+        want = O.phat_correlation(a, b)
+        print(f"  L={L} n={info['n']} = {info['n1']} x {info['n2']} tile {info['tile_len']}: pfa-oracle {np.max(np.abs(got - want)):.3e} "
+              f"4step-oracle {np.max(np.abs(ref - want)):.3e} pfa-4step {np.max(np.abs(got - ref)):.3e} argmax {np.argmax(got)} {np.argmax(want)}", flush=True)
+    frames = rng.standard_normal((1, 5, 3000)); frames[:, 1:] += 0.5 * frames[:, :1]
+    tp, cp = ep.gcc_phat_all_pairs(frames, 16000.0, max_expected_delay=0.004, want_corr=True)
+    t4, c4 = e4.gcc_phat_all_pairs(frames, 16000.0, max_expected_delay=0.004, want_corr=True)
+    print(f"  all-pairs 5 mics (odd pair count): corr diff {np.max(np.abs(cp - c4)):.3e} k_sel eq {np.array_equal(tp['k_sel'], t4['k_sel'])}", flush=True)
+
+
+if "pfa" in sys.argv[1:]:
+    section("pfa", pfa)
+
 if "stamps" in sys.argv[1:]:
     section("stamps", stamps)
