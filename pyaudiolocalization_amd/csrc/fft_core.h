@@ -259,29 +259,42 @@ template <int LOG2N, int T> struct LdsTile3 {
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------- workgroup transform (device)
+// One stage: every lane loads its work items through `in`, all LDS reads finish before any LDS write (in
+// place), outputs go to `out`, and LDS outputs are visible to all lanes on return.
+template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB, bool COMPACT, class In, class Out>
+__device__ __forceinline__ void wg_stage(const cd* tw, int tid, const In& in, const Out& out) {
+  constexpr int R = stage_radix(LOG2N, LOG2P);
+  constexpr int POINTS = NSUB << LOG2N, LANES = POINTS / 16;   // 16 points per lane: 256 lanes (192 with a radix-3 stage)
+  constexpr int PER = POINTS / R / LANES;                      // work items per lane: 1, 2, 4 or 8
+  cd v[PER][R];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) stage_load<LOG2N, COLS, INV, LOG2P, NSUB, COMPACT>(in, tw, tid + LANES * q, v[q]);
+  if constexpr (In::kLds && Out::kLds) __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PER; ++q) stage_store<LOG2N, COLS, LOG2P, NSUB>(out, tid + LANES * q, v[q]);
+  if constexpr (Out::kLds) __syncthreads();
+}
+
 template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB, bool COMPACT, class FirstIn, class LastOut>
 __device__ __forceinline__ void wg_fft_from(cd* data, const cd* tw, int tid, const FirstIn& first, const LastOut& last) {
   if constexpr (LOG2P < LOG2N) {
-    constexpr int R = stage_radix(LOG2N, LOG2P);
-    constexpr int POINTS = NSUB << LOG2N, LANES = POINTS / 16;   // 16 points per lane: 256 lanes (192 with a radix-3 stage)
-    constexpr int PER = POINTS / R / LANES;                      // work items per lane: 1, 2, 4 or 8
     constexpr bool kFirst = LOG2P == 0, kLast = stage_is_last(LOG2N, LOG2P);
-    constexpr bool in_lds = !kFirst || FirstIn::kLds, out_lds = !kLast || LastOut::kLds;
     const LdsTile<LOG2N, COLS, NSUB> tile{data};
-    cd v[PER][R];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      if constexpr (kFirst) stage_load<LOG2N, COLS, INV, LOG2P, NSUB, COMPACT>(first, tw, tid + LANES * q, v[q]);
-      else stage_load<LOG2N, COLS, INV, LOG2P, NSUB, COMPACT>(tile, tw, tid + LANES * q, v[q]);
-    }
-    if constexpr (in_lds && out_lds) __syncthreads();            // in place: every read before any write
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      if constexpr (kLast) stage_store<LOG2N, COLS, LOG2P, NSUB>(last, tid + LANES * q, v[q]);
-      else stage_store<LOG2N, COLS, LOG2P, NSUB>(tile, tid + LANES * q, v[q]);
-    }
-    if constexpr (out_lds) __syncthreads();
+    if constexpr (kFirst && kLast) wg_stage<LOG2N, COLS, INV, LOG2P, NSUB, COMPACT>(tw, tid, first, last);
+    else if constexpr (kFirst) wg_stage<LOG2N, COLS, INV, LOG2P, NSUB, COMPACT>(tw, tid, first, tile);
+    else if constexpr (kLast) wg_stage<LOG2N, COLS, INV, LOG2P, NSUB, COMPACT>(tw, tid, tile, last);
+    else wg_stage<LOG2N, COLS, INV, LOG2P, NSUB, COMPACT>(tw, tid, tile, tile);
     wg_fft_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P), NSUB, COMPACT>(data, tw, tid, first, last);
+  }
+}
+
+// the LDS-to-LDS stages from LOG2P up to, not including, the last one
+template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB, bool COMPACT>
+__device__ __forceinline__ void wg_fft_middle(cd* data, const cd* tw, int tid) {
+  if constexpr (!stage_is_last(LOG2N, LOG2P)) {
+    const LdsTile<LOG2N, COLS, NSUB> tile{data};
+    wg_stage<LOG2N, COLS, INV, LOG2P, NSUB, COMPACT>(tw, tid, tile, tile);
+    wg_fft_middle<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P), NSUB, COMPACT>(data, tw, tid);
   }
 }
 

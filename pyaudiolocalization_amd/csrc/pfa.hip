@@ -24,196 +24,9 @@
 #include <cmath>
 #include <vector>
 
-#include "conv_kernels.h"
+#include "pfa_kernels.h"
 
 namespace pal {
-
-constexpr int kPfaTC = 22;   // accumulator pairs per lane of the column pass
-
-// ------------------------------------------------------------------ permuted spectra
-// SP[row][k1][k2] = full Hermitian-extended spectrum at k = (e1 k1 + e2 k2) mod n, for k1 < NR
-__global__ void k_pfa_permute(const cd* __restrict__ S, cd* __restrict__ SP, int n, int H, int NR, int N2,
-                              long long e1, long long e2) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= NR * N2) return;
-  const int k1 = idx / N2, k2 = idx - k1 * N2;
-  const long long k = (e1 * k1 + e2 * k2) % n;
-  const cd* row = S + size_t(blockIdx.y) * H;
-  cd v;
-  if (k < H) v = row[k];
-  else v = cconj(row[n - k]);
-  SP[(size_t(blockIdx.y) * NR + k1) * N2 + k2] = v;
-}
-
-// ------------------------------------------------------------------ stage functors of the row pass
-template <int LM> struct PfaIn {          // first stage of the forward FFT: whitened pair values times the chirp
-  static constexpr bool kLds = false;
-  const cd *sa, *sb, *sc, *sd;            // row k1 of the four mic spectra (sc = sa / sd = sb when unused)
-  const cd* b;
-  int N2;
-  bool second, share;
-  __device__ cd operator()(int t, int e) const {
-    constexpr int HALF = 1 << (LM - 1);   // N2 <= M/2: the upper half of every tile is zero padding
-    if (e >= HALF) return mk(0, 0);
-    const int ee = e < N2 ? e : N2 - 1;
-    const cd a = sa[ee];
-    const cd r1 = whiten(a, sb[ee]);
-    cd r2 = mk(0, 0);
-    if (second) r2 = whiten(share ? a : sc[ee], sd[ee]);
-    // tile 0: R^p + i R^q at (k1, e);  tile 1: conj(R^p) + i conj(R^q) = the reversed row N1 - k1
-    const cd x = t == 0 ? mk(r1.x - r2.y, r1.y + r2.x) : mk(r1.x + r2.y, r2.x - r1.y);
-    const cd y = cmul(x, b[ee]);
-    return e < N2 ? y : mk(0, 0);
-  }
-};
-
-template <int LM> struct PfaHhatToLds {   // last stage of the forward FFT: times the chirp spectrum, into LDS
-  static constexpr bool kLds = true;
-  cd* data;
-  const cd* hh;
-  __device__ void operator()(int t, int e, cd v) const { data[lds_addr<LM, false, 2>(t, e)] = cmul(v, hh[e]); }
-};
-
-template <int LM> struct PfaOut {         // last stage of the inverse FFT: chirp, column twiddle, store Y[row][m2]
-  static constexpr bool kLds = false;
-  cd* Yg;                                 // Y of this transform: [N1][N2]
-  const cd *b, *r1;
-  int N1, N2, k1, uk0, uk1;               // uk_t = u1 * row_t mod N1
-  float inv;
-  __device__ void operator()(int t, int e, cd v) const {
-    constexpr int HALF = 1 << (LM - 1);
-    if (e >= HALF) return;
-    const int ee = e < N2 ? e : N2 - 1;
-    const int m2 = t == 0 ? ee : (ee ? N2 - ee : 0);
-    const int row = t == 0 ? k1 : N1 - k1;
-    const unsigned x = unsigned(t == 0 ? uk0 : uk1) * unsigned(m2);     // < 2^24: exact in float
-    const unsigned q = unsigned(float(x) * inv);
-    int r = int(x) - int(q) * N1;
-    if (r < 0) r += N1;
-    if (r >= N1) r -= N1;
-    const cd z = cmulc(cmul(v, b[ee]), r1[r]);                           // r1 holds exp(-2 pi i q / N1)
-    if (e < N2 && !(t == 1 && k1 == 0)) Yg[size_t(row) * N2 + m2] = z;
-  }
-};
-
-template <int LM> struct PfaChirpIn {     // chirp kernel of the convolution: h[d mod M] = conj(b[|d|]), |d| < N2
-  static constexpr bool kLds = false;
-  const cd* b;
-  int N2;
-  __device__ cd operator()(int, int e) const {
-    constexpr int M = 1 << LM;
-    if (e < N2) return cconj(b[e]);
-    if (M - e < N2) return cconj(b[M - e]);
-    return mk(0, 0);
-  }
-};
-
-template <int LM> struct PfaScaledOut {
-  static constexpr bool kLds = false;
-  cd* out;
-  double scale;
-  __device__ void operator()(int t, int e, cd v) const { if (t == 0) out[e] = cscale(v, scale); }
-};
-
-template <int LM> struct PfaLds {         // LDS sizes of the row pass
-  static constexpr bool kCompact = LM >= 11;
-  static constexpr int kM = 1 << LM, kLanes = 2 * kM / 16;
-  static constexpr int kTw = kCompact ? stage_twc_size(LM) : stage_tw_size(LM);
-};
-
-template <int LM>
-__global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_hhat(const cd* __restrict__ b, int N2, cd* __restrict__ hhat,
-                                                                 double scale, const cd* __restrict__ tws) {
-  using L = PfaLds<LM>;
-  __shared__ cd data[2 * L::kM];
-  __shared__ cd tw[L::kTw];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < L::kTw; i += L::kLanes) tw[i] = tws[i];
-  wg_fft<LM, false, false, 2, L::kCompact>(data, tw, tid, PfaChirpIn<LM>{b, N2}, PfaScaledOut<LM>{hhat, scale});
-}
-
-struct PfaRowsArgs {
-  const cd* SP;        // permuted spectra [mic][NR][N2]
-  const int4* quad;    // mic rows (a, b) of pair p and (c, d) of pair q; c < 0: no second pair
-  cd* Y;               // [G][N1][N2]
-  const cd *b, *hhat, *r1, *tws;
-  int N1, N2, NR, G, u1;
-  float inv;
-};
-
-// grid = G * NR workgroups, transform fastest so that neighbours share the tables
-template <int LM>
-__global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) {
-  using L = PfaLds<LM>;
-  __shared__ cd data[2 * L::kM];
-  __shared__ cd tw[L::kTw];
-  const int tid = threadIdx.x;
-  const int g = blockIdx.x % a.G, k1 = blockIdx.x / a.G;
-  for (int i = tid; i < L::kTw; i += L::kLanes) tw[i] = a.tws[i];
-  const int4 q = a.quad[g];
-  const size_t mic = size_t(a.NR) * a.N2, off = size_t(k1) * a.N2;
-  const bool second = q.z >= 0;
-  const cd* sa = a.SP + size_t(q.x) * mic + off;
-  const cd* sb = a.SP + size_t(q.y) * mic + off;
-  const PfaIn<LM> in{sa, sb, second ? a.SP + size_t(q.z) * mic + off : sa, second ? a.SP + size_t(q.w) * mic + off : sb,
-                     a.b, a.N2, second, second && q.z == q.x};
-  wg_fft<LM, false, false, 2, L::kCompact>(data, tw, tid, in, PfaHhatToLds<LM>{data, a.hhat});
-  const int kr = k1 ? a.N1 - k1 : 0;
-  const PfaOut<LM> out{a.Y + size_t(g) * a.N1 * a.N2, a.b, a.r1, a.N1, a.N2, k1, (a.u1 * k1) % a.N1, (a.u1 * kr) % a.N1, a.inv};
-  wg_fft<LM, false, true, 2, L::kCompact>(data, tw, tid, LdsTile<LM, false, 2>{data}, out);
-}
-
-// ------------------------------------------------------------------ column pass
-// One lane per column m2 (64 consecutive columns per wavefront: coalesced 1 KB loads of Y, 512 B stores of a
-// correlation row).  The four wavefronts of a workgroup split the work by role (pair p = real parts, pair q =
-// imaginary parts) and by chunk of kPfaTC output indices t; with E_j = Y_j + Y_{N1-j}, O_j = Y_j - Y_{N1-j}:
-//   p:  c[t] = Re Y_0 + sum_j cos(j t) Re E_j - sum_j sin(j t) Im O_j,   c[N1-t] = the same with + sin
-//   q:  c[t] = Im Y_0 + sum_j cos(j t) Im E_j + sum_j sin(j t) Re O_j,   c[N1-t] = the same with - sin
-// The cos / sin rows are wave-uniform: T[(j-1)][chunk][cos | sin][tt] is read through scalar loads.
-template <int TC>
-__global__ __launch_bounds__(256) void k_pfa_cols(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
-                                                  int N1, int N2, int G, int nch, const double* __restrict__ T) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
-  const int role = wave & 1, ch = int(blockIdx.y) * 2 + (wave >> 1);
-  if (ch >= nch) return;
-  const int g = blockIdx.x % G, cb = blockIdx.x / G;
-  const int m2 = cb * 64 + lane;
-  const bool live = m2 < N2;
-  const cd* Yg = Y + size_t(g) * N1 * N2 + (live ? m2 : N2 - 1);
-  const int h = (N1 - 1) / 2;
-  double accC[TC], accS[TC];
-#pragma unroll
-  for (int tt = 0; tt < TC; ++tt) accC[tt] = accS[tt] = 0.0;
-  double sumE = 0.0;
-  const double* Tj = T + size_t(ch) * 2 * TC;
-  const size_t tstep = size_t(nch) * 2 * TC;
-  for (int j = 1; j <= h; ++j, Tj += tstep) {
-    const cd yj = Yg[size_t(j) * N2], ym = Yg[size_t(N1 - j) * N2];
-    const double a = role ? yj.y + ym.y : yj.x + ym.x;
-    const double b = role ? yj.x - ym.x : yj.y - ym.y;
-    sumE += a;
-#pragma unroll
-    for (int tt = 0; tt < TC; ++tt) {
-      accC[tt] = __builtin_fma(Tj[tt], a, accC[tt]);
-      accS[tt] = __builtin_fma(Tj[TC + tt], b, accS[tt]);
-    }
-  }
-  const cd y0 = Yg[0];
-  const double base = role ? y0.y : y0.x;
-  if (!live) return;
-  double* out = corr + size_t(2 * g + role) * stride + m2;
-  if (ch == 0) out[0] = base + sumE;
-#pragma unroll
-  for (int tt = 0; tt < TC; ++tt) {
-    const int t = ch * TC + tt + 1;
-    if (t <= h) {
-      const double s = role ? accS[tt] : -accS[tt];
-      out[size_t(N2) * t] = base + accC[tt] + s;
-      out[size_t(N2) * (N1 - t)] = base + accC[tt] - s;
-    }
-  }
-}
 
 // ------------------------------------------------------------------ plan
 static long long inv_mod(long long a, long long m) {   // a^-1 mod m (gcd = 1), 0 when m == 1
@@ -316,7 +129,7 @@ int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads
     char name[48];
     snprintf(name, sizeof name, "k_pfa_rows<%d>", f.lm);
     ProfScope ps(this, name, on);
-    PfaRowsArgs a{permuted, quads, Y, f.b, f.hhat, f.r1, tws, f.n1, f.n2, f.rows(), G, f.u1, 1.0f / float(f.n1)};
+    PfaRowsArgs a{permuted, quads, Y, f.b, f.hhat, f.r1, tws, f.n1, f.n2, f.rows(), G, f.u1, 1.0f / float(f.n1), nullptr};
     const unsigned grid = unsigned(G) * unsigned(f.rows());
     PAL_SWITCH_LM(f.lm, k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, on>>>(a));
     PAL_HIP(hipGetLastError());

@@ -1,0 +1,284 @@
+// pfa_kernels.h - device side of the prime-factor route (see pfa.hip for the algorithm); a header so that
+// tools/microbench_pfa.hip can time the same kernels with ablated functors.
+#pragma once
+#include "conv_kernels.h"
+
+namespace pal {
+
+constexpr int kPfaTC = 22;   // accumulator pairs per lane of the column pass
+
+// ------------------------------------------------------------------ permuted spectra
+// SP[row][k1][k2] = full Hermitian-extended spectrum at k = (e1 k1 + e2 k2) mod n, for k1 < NR
+__global__ void k_pfa_permute(const cd* __restrict__ S, cd* __restrict__ SP, int n, int H, int NR, int N2,
+                              long long e1, long long e2) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NR * N2) return;
+  const int k1 = idx / N2, k2 = idx - k1 * N2;
+  const long long k = (e1 * k1 + e2 * k2) % n;
+  const cd* row = S + size_t(blockIdx.y) * H;
+  cd v;
+  if (k < H) v = row[k];
+  else v = cconj(row[n - k]);
+  SP[(size_t(blockIdx.y) * NR + k1) * N2 + k2] = v;
+}
+
+// ------------------------------------------------------------------ stage functors of the row pass
+template <int LM> struct PfaHhatToLds {   // last stage of the forward FFT: times the chirp spectrum, into LDS
+  static constexpr bool kLds = true;
+  cd* data;
+  const cd* hh;
+  __device__ void operator()(int t, int e, cd v) const { data[lds_addr<LM, false, 2>(t, e)] = cmul(v, hh[e]); }
+};
+
+template <int LM> struct PfaOut {         // last stage of the inverse FFT: chirp, column twiddle, store Y[row][m2]
+  static constexpr bool kLds = false;
+  cd* Yg;                                 // Y of this transform: [N1][N2]
+  const cd *b, *r1;
+  int N1, N2, k1, uk0, uk1;               // uk_t = u1 * row_t mod N1
+  float inv;
+  __device__ void operator()(int t, int e, cd v) const {
+    constexpr int HALF = 1 << (LM - 1);
+    if (e >= HALF) return;
+    const int ee = e < N2 ? e : N2 - 1;
+    const int m2 = t == 0 ? ee : (ee ? N2 - ee : 0);
+    const int row = t == 0 ? k1 : N1 - k1;
+    const unsigned x = unsigned(t == 0 ? uk0 : uk1) * unsigned(m2);     // < 2^24: exact in float
+    const unsigned q = unsigned(float(x) * inv);
+    int r = int(x) - int(q) * N1;
+    if (r < 0) r += N1;
+    if (r >= N1) r -= N1;
+    const cd z = cmulc(cmul(v, b[ee]), r1[r]);                           // r1 holds exp(-2 pi i q / N1)
+    if (e < N2 && !(t == 1 && k1 == 0)) Yg[size_t(row) * N2 + m2] = z;
+  }
+};
+
+template <int LM> struct PfaChirpIn {     // chirp kernel of the convolution: h[d mod M] = conj(b[|d|]), |d| < N2
+  static constexpr bool kLds = false;
+  const cd* b;
+  int N2;
+  __device__ cd operator()(int, int e) const {
+    constexpr int M = 1 << LM;
+    if (e < N2) return cconj(b[e]);
+    if (M - e < N2) return cconj(b[M - e]);
+    return mk(0, 0);
+  }
+};
+
+template <int LM> struct PfaScaledOut {
+  static constexpr bool kLds = false;
+  cd* out;
+  double scale;
+  __device__ void operator()(int t, int e, cd v) const { if (t == 0) out[e] = cscale(v, scale); }
+};
+
+template <int LM> struct PfaLds {         // LDS sizes of the row pass
+  static constexpr bool kCompact = LM >= 11;
+  static constexpr int kM = 1 << LM, kLanes = 2 * kM / 16;
+  static constexpr int kTw = kCompact ? stage_twc_size(LM) : stage_tw_size(LM);
+};
+
+template <int LM>
+__global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_hhat(const cd* __restrict__ b, int N2, cd* __restrict__ hhat,
+                                                                 double scale, const cd* __restrict__ tws) {
+  using L = PfaLds<LM>;
+  __shared__ cd data[2 * L::kM];
+  __shared__ cd tw[L::kTw];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < L::kTw; i += L::kLanes) tw[i] = tws[i];
+  wg_fft<LM, false, false, 2, L::kCompact>(data, tw, tid, PfaChirpIn<LM>{b, N2}, PfaScaledOut<LM>{hhat, scale});
+}
+
+struct PfaRowsArgs {
+  const cd* SP;        // permuted spectra [mic][NR][N2]
+  const int4* quad;    // mic rows (a, b) of pair p and (c, d) of pair q; c < 0: no second pair
+  cd* Y;               // [G][N1][N2]
+  const cd *b, *hhat, *r1, *tws;
+  int N1, N2, NR, G, u1;
+  float inv;
+  unsigned long long* stamps;   // diagnostics only (tools/microbench_pfa): 100 MHz clock reads of lane 0 per phase
+};
+
+// partner lane's value across the two halves of a wavefront (lane ^ 32)
+__device__ __forceinline__ double swap_halves(double v, bool upper) {
+  const unsigned lo = unsigned(__double2loint(v)), hi = unsigned(__double2hiint(v));
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(int(upper ? b[0] : b[1]), int(upper ? a[0] : a[1]));
+}
+
+// grid = G * NR workgroups, transform fastest so that neighbours share the tables.
+//
+// Stage plan of one workgroup (two tiles of M points, 16 points per lane):
+//   1. first forward stage, hand-mapped: the two halves of a wavefront own the same butterfly index i of
+//      tile 0 and tile 1.  Both tiles are built from the SAME whitened bins (tile 1 is the conjugate
+//      combination), so each half whitens four of the eight non-zero inputs and the halves trade the other
+//      tile's values with v_permlane32_swap - no LDS, no barrier, half the loads and reciprocal square roots.
+//   2. the LDS-to-LDS middle stages of the forward transform.
+//   3. fused seam: the last forward stage, the product with the chirp spectrum and the first inverse stage
+//      run on the same sixteen registers (the last stage's outputs k + P r are exactly the inputs
+//      i + (M/16) r' of a first-stage butterfly), which saves one LDS round trip and two barriers.
+//   4. the remaining inverse stages; the last one hands Y to global memory.
+template <int LM>
+__global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) {
+  using L = PfaLds<LM>;
+  constexpr int M = L::kM, NB = M / 16;
+  constexpr bool CT = L::kCompact;
+  static_assert(stage_log2r(LM, 0) == 4, "the hand-mapped stages assume a radix-16 first stage");
+  __shared__ cd data[2 * M];
+  __shared__ cd tw[L::kTw];
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x % a.G, k1 = blockIdx.x / a.G;
+  unsigned long long* const stamps = a.stamps;
+  int stamp_at = 0;
+  auto stamp = [&]() {
+    if (stamps && tid == 0) stamps[size_t(blockIdx.x) * 8 + stamp_at] = __builtin_amdgcn_s_memrealtime();
+    ++stamp_at;
+  };
+  stamp();
+  // the twiddle rows travel global -> registers -> LDS; their loads are issued first and land while the pair
+  // table and the spectrum rows are being fetched
+  constexpr int kTwPer = (L::kTw + L::kLanes - 1) / L::kLanes;
+  cd twr[kTwPer];
+#pragma unroll
+  for (int q = 0; q < kTwPer; ++q) {
+    const int idx = tid + q * L::kLanes;
+    twr[q] = a.tws[idx < L::kTw ? idx : L::kTw - 1];
+  }
+  const LdsTile<LM, false, 2> tile{data};
+
+  // ---- 1. first forward stage
+  {
+    const int4 q = a.quad[g];
+    const size_t mic = size_t(a.NR) * a.N2, off = size_t(k1) * a.N2;
+    const bool second = q.z >= 0;
+    const cd* sa = a.SP + size_t(q.x) * mic + off;
+    const cd* sb = a.SP + size_t(q.y) * mic + off;
+    const cd* sc = second ? a.SP + size_t(q.z) * mic + off : sa;   // branch-free loads: a missing second pair re-reads
+    const cd* sd = second ? a.SP + size_t(q.w) * mic + off : sb;   // the first one (cache hits) and is zeroed below
+    const double keep2 = second ? 1.0 : 0.0;
+    const bool upper = (tid >> 5) & 1;                        // upper half of the wavefront = tile 1
+    const int i = (tid & 31) | ((tid >> 6) << 5);             // butterfly index, < NB
+    cd va[4], vb[4], vc[4], vd[4], ch[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                             // all twenty loads in flight before the first use
+      const int e = i + NB * (u + (upper ? 4 : 0));           // < M/2; N2 <= M/2, the rest is zero padding
+      const int ee = e < a.N2 ? e : a.N2 - 1;
+      va[u] = sa[ee]; vb[u] = sb[ee]; vc[u] = sc[ee]; vd[u] = sd[ee];
+      ch[u] = a.b[ee];
+    }
+#pragma unroll
+    for (int q = 0; q < kTwPer; ++q) {
+      const int idx = tid + q * L::kLanes;
+      if (idx < L::kTw) tw[idx] = twr[q];
+    }
+    cd mine[4], recv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = i + NB * (u + (upper ? 4 : 0));
+      const cd r1 = whiten(va[u], vb[u]);
+      const cd r2 = cscale(whiten(vc[u], vd[u]), keep2);
+      // tile 0: R^p + i R^q at (k1, e);  tile 1: conj(R^p) + i conj(R^q) = the reversed row N1 - k1
+      cd x = cmul(mk(r1.x - r2.y, r1.y + r2.x), ch[u]), z = cmul(mk(r1.x + r2.y, r2.x - r1.y), ch[u]);
+      if (e >= a.N2) x = z = mk(0, 0);
+      mine[u] = upper ? z : x;
+      const cd send = upper ? x : z;
+      recv[u] = mk(swap_halves(send.x, upper), swap_halves(send.y, upper));
+    }
+    cd v[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = upper ? recv[u] : mine[u];
+      v[4 + u] = upper ? mine[u] : recv[u];
+      v[8 + u] = v[12 + u] = mk(0, 0);
+    }
+    dft16<false>(v);
+    stage_store<LM, false, 0, 2>(tile, (upper ? NB : 0) + i, v);
+    __syncthreads();                                          // also publishes `tw`
+  }
+  stamp();
+
+  // ---- 2. forward middle stages
+  wg_fft_middle<LM, false, false, 4, 2, CT>(data, tw, tid);
+  stamp();
+
+  // ---- 3. last forward stage x chirp spectrum x first inverse stage
+  {
+    constexpr int LPL = stage_tw_last(LM), RL = stage_radix(LM, LPL), P = 1 << LPL, SPLIT = 16 / RL;
+    static_assert(RL == 8 || RL == 16, "last-stage radix");
+    const int t = tid / NB, i = tid % NB;
+    cd u[16];
+#pragma unroll
+    for (int q = 0; q < SPLIT; ++q) {
+      cd v[RL];
+      const int k = i + NB * q;                               // < P: butterfly of the last stage, outputs k + P r
+      stage_load<LM, false, false, LPL, 2, CT>(tile, tw, t * P + k, v);
+#pragma unroll
+      for (int r = 0; r < RL; ++r) u[q + SPLIT * r] = cmul(v[r], a.hhat[k + P * r]);
+    }
+    __syncthreads();                                          // every lane has read its inputs
+    dft16<true>(u);
+    stage_store<LM, false, 0, 2>(tile, tid, u);
+    __syncthreads();
+  }
+  stamp();
+
+  // ---- 4. remaining inverse stages
+  const int kr = k1 ? a.N1 - k1 : 0;
+  const PfaOut<LM> out{a.Y + size_t(g) * a.N1 * a.N2, a.b, a.r1, a.N1, a.N2, k1, (a.u1 * k1) % a.N1, (a.u1 * kr) % a.N1, a.inv};
+  wg_fft_from<LM, false, true, 4, 2, CT>(data, tw, tid, tile, out);
+  stamp();
+}
+
+// ------------------------------------------------------------------ column pass
+// One lane per column m2 (64 consecutive columns per wavefront: coalesced 1 KB loads of Y, 512 B stores of a
+// correlation row).  The four wavefronts of a workgroup split the work by role (pair p = real parts, pair q =
+// imaginary parts) and by chunk of kPfaTC output indices t; with E_j = Y_j + Y_{N1-j}, O_j = Y_j - Y_{N1-j}:
+//   p:  c[t] = Re Y_0 + sum_j cos(j t) Re E_j - sum_j sin(j t) Im O_j,   c[N1-t] = the same with + sin
+//   q:  c[t] = Im Y_0 + sum_j cos(j t) Im E_j + sum_j sin(j t) Re O_j,   c[N1-t] = the same with - sin
+// The cos / sin rows are wave-uniform: T[(j-1)][chunk][cos | sin][tt] is read through scalar loads.
+template <int TC>
+__global__ __launch_bounds__(256) void k_pfa_cols(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
+                                                  int N1, int N2, int G, int nch, const double* __restrict__ T) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+  const int role = wave & 1, ch = int(blockIdx.y) * 2 + (wave >> 1);
+  if (ch >= nch) return;
+  const int g = blockIdx.x % G, cb = blockIdx.x / G;
+  const int m2 = cb * 64 + lane;
+  const bool live = m2 < N2;
+  const cd* Yg = Y + size_t(g) * N1 * N2 + (live ? m2 : N2 - 1);
+  const int h = (N1 - 1) / 2;
+  double accC[TC], accS[TC];
+#pragma unroll
+  for (int tt = 0; tt < TC; ++tt) accC[tt] = accS[tt] = 0.0;
+  double sumE = 0.0;
+  const double* Tj = T + size_t(ch) * 2 * TC;
+  const size_t tstep = size_t(nch) * 2 * TC;
+  for (int j = 1; j <= h; ++j, Tj += tstep) {
+    const cd yj = Yg[size_t(j) * N2], ym = Yg[size_t(N1 - j) * N2];
+    const double a = role ? yj.y + ym.y : yj.x + ym.x;
+    const double b = role ? yj.x - ym.x : yj.y - ym.y;
+    sumE += a;
+#pragma unroll
+    for (int tt = 0; tt < TC; ++tt) {
+      accC[tt] = __builtin_fma(Tj[tt], a, accC[tt]);
+      accS[tt] = __builtin_fma(Tj[TC + tt], b, accS[tt]);
+    }
+  }
+  const cd y0 = Yg[0];
+  const double base = role ? y0.y : y0.x;
+  if (!live) return;
+  double* out = corr + size_t(2 * g + role) * stride + m2;
+  if (ch == 0) out[0] = base + sumE;
+#pragma unroll
+  for (int tt = 0; tt < TC; ++tt) {
+    const int t = ch * TC + tt + 1;
+    if (t <= h) {
+      const double s = role ? accS[tt] : -accS[tt];
+      out[size_t(N2) * t] = base + accC[tt] + s;
+      out[size_t(N2) * (N1 - t)] = base + accC[tt] - s;
+    }
+  }
+}
+
+}  // namespace pal

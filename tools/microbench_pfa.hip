@@ -1,0 +1,219 @@
+// Ablation timings of the prime-factor kernels on the metric geometry (n = 88199 = 89 x 991, G transforms).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-signed-zeros -I pyaudiolocalization_amd/csrc -I include \
+//         tools/microbench_pfa.hip -o tools/microbench_pfa
+// Random data (the timing does not depend on values); not part of the product or the tests.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "pfa_kernels.h"
+
+using namespace pal;
+
+namespace pal {   // the table generators live in bluestein.hip; the microbench only needs valid memory
+__global__ void k_make_chirp(cd*, int, int) {}
+__global__ void k_make_roots(cd*, int, double) {}
+__global__ void k_make_stage_tw(cd*, int, bool) {}
+}
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// ---- column pass variants: MODE 0 product shape, 1 no table loads, 2 no Y loads; UNR = j-steps per load batch
+template <int TC, int MODE, int UNR>
+__global__ __launch_bounds__(256) void cols_var(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
+                                                int N1, int N2, int G, int nch, const double* __restrict__ T) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+  const int role = wave & 1, ch = int(blockIdx.y) * 2 + (wave >> 1);
+  if (ch >= nch) return;
+  const int g = blockIdx.x % G, cb = blockIdx.x / G;
+  const int m2 = cb * 64 + lane;
+  const bool live = m2 < N2;
+  const cd* Yg = Y + size_t(g) * N1 * N2 + (live ? m2 : N2 - 1);
+  const int h = (N1 - 1) / 2;
+  double accC[TC], accS[TC];
+#pragma unroll
+  for (int tt = 0; tt < TC; ++tt) accC[tt] = accS[tt] = 0.0;
+  double sumE = 0.0;
+  const double* Tj = T + size_t(ch) * 2 * TC;
+  const size_t tstep = size_t(nch) * 2 * TC;
+  for (int j = 1; j + UNR - 1 <= h; j += UNR) {
+    cd yj[UNR], ym[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (MODE == 2) { yj[u] = mk(double(j + u), 1.0); ym[u] = mk(0.5, double(lane)); }
+      else { yj[u] = Yg[size_t(j + u) * N2]; ym[u] = Yg[size_t(N1 - j - u) * N2]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u, Tj += tstep) {
+      const double a = role ? yj[u].y + ym[u].y : yj[u].x + ym[u].x;
+      const double b = role ? yj[u].x - ym[u].x : yj[u].y - ym[u].y;
+      sumE += a;
+#pragma unroll
+      for (int tt = 0; tt < TC; ++tt) {
+        const double c = MODE == 1 ? 0.25 * (tt + 1) : Tj[tt], s = MODE == 1 ? 0.125 * (tt + 2) : Tj[TC + tt];
+        accC[tt] = __builtin_fma(c, a, accC[tt]);
+        accS[tt] = __builtin_fma(s, b, accS[tt]);
+      }
+    }
+  }
+  const cd y0 = Yg[0];
+  const double base = role ? y0.y : y0.x;
+  if (!live) return;
+  double* out = corr + size_t(2 * g + role) * stride + m2;
+  if (ch == 0) out[0] = base + sumE;
+#pragma unroll
+  for (int tt = 0; tt < TC; ++tt) {
+    const int t = ch * TC + tt + 1;
+    if (t <= h) {
+      const double s = role ? accS[tt] : -accS[tt];
+      out[size_t(N2) * t] = base + accC[tt] + s;
+      out[size_t(N2) * (N1 - t)] = base + accC[tt] - s;
+    }
+  }
+}
+
+// ---- row pass variants
+template <int LM> struct ConstIn {
+  static constexpr bool kLds = false;
+  __device__ cd operator()(int t, int e) const { return e >= (1 << (LM - 1)) ? mk(0, 0) : mk(double(e), double(t)); }
+};
+template <int LM> struct ConstHhat {
+  static constexpr bool kLds = true;
+  cd* data;
+  __device__ void operator()(int t, int e, cd v) const { data[lds_addr<LM, false, 2>(t, e)] = cmul(v, mk(0.5, 0.25)); }
+};
+template <int LM> struct Sink {
+  static constexpr bool kLds = false;
+  cd* base;
+  __device__ void operator()(int t, int e, cd v) const { if (e < (1 << (LM - 1)) && v.x == 123.456) base[0] = v; }
+};
+
+template <int LM, int MODE>   // 1 = compute only, 2 = memory only
+__global__ __launch_bounds__(PfaLds<LM>::kLanes) void rows_var(PfaRowsArgs a) {
+  using L = PfaLds<LM>;
+  __shared__ cd data[2 * L::kM];
+  __shared__ cd tw[L::kTw];
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x % a.G, k1 = blockIdx.x / a.G;
+  for (int i = tid; i < L::kTw; i += L::kLanes) tw[i] = a.tws[i];
+  if (MODE == 1) {
+    wg_fft<LM, false, false, 2, L::kCompact>(data, tw, tid, ConstIn<LM>{}, ConstHhat<LM>{data});
+    wg_fft<LM, false, true, 2, L::kCompact>(data, tw, tid, LdsTile<LM, false, 2>{data}, Sink<LM>{a.Y});
+  } else {
+    const int4 q = a.quad[g];
+    const size_t mic = size_t(a.NR) * a.N2, off = size_t(k1) * a.N2;
+    const cd* sa = a.SP + size_t(q.x) * mic + off;
+    const cd* sb = a.SP + size_t(q.y) * mic + off;
+    const cd* sc = a.SP + size_t(q.z) * mic + off;
+    const cd* sd = a.SP + size_t(q.w) * mic + off;
+    const bool share = q.z == q.x;
+    const int t = tid / (L::kLanes / 2), i = tid % (L::kLanes / 2);
+    cd* Yg = a.Y + size_t(g) * a.N1 * a.N2;
+    const int row = t == 0 ? k1 : (k1 ? a.N1 - k1 : 0);
+    for (int r = 0; r < 8; ++r) {
+      const int e = i + r * (L::kLanes / 2);
+      const int ee = e < a.N2 ? e : a.N2 - 1;
+      const cd va = sa[ee], vb = sb[ee], vd = sd[ee];
+      const cd vc = share ? va : sc[ee];
+      cd z = mk(va.x + vb.x + vc.x + vd.x, va.y + vb.y + vc.y + vd.y);
+      z = cmul(z, a.b[ee]);
+      z = cmul(z, a.hhat[e]);
+      z = cmul(z, a.hhat[e + (1 << (LM - 1))]);
+      if (e < a.N2) Yg[size_t(row) * a.N2 + (t ? (ee ? a.N2 - ee : 0) : ee)] = z;
+    }
+  }
+}
+
+template <class F> static float time_it(const char* name, int reps, F launch) {
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  launch();
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  for (int i = 0; i < reps; ++i) launch();
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, a, b));
+  CHECK(hipGetLastError());
+  printf("  %-44s %8.1f us\n", name, ms * 1000.0f / reps);
+  return ms / reps;
+}
+
+int main(int argc, char** argv) {
+  const int G = argc > 1 ? atoi(argv[1]) : 128;
+  const int N1 = 89, N2 = 991, NR = 45, mics = 64, n = N1 * N2;
+  constexpr int LM = 11;
+  const size_t stride = size_t(n) + 1;
+  cd *SP, *Y, *b, *hhat, *r1, *tws;
+  double *corr, *T;
+  int4* quad;
+  CHECK(hipMalloc(&SP, sizeof(cd) * mics * NR * N2));
+  CHECK(hipMalloc(&Y, sizeof(cd) * size_t(G) * n));
+  CHECK(hipMalloc(&b, sizeof(cd) * N2));
+  CHECK(hipMalloc(&hhat, sizeof(cd) << LM));
+  CHECK(hipMalloc(&r1, sizeof(cd) * N1));
+  CHECK(hipMalloc(&tws, sizeof(cd) << LM));
+  CHECK(hipMalloc(&corr, sizeof(double) * 2 * G * stride));
+  const int h = 44, nch = 2;
+  CHECK(hipMalloc(&T, sizeof(double) * h * nch * 2 * kPfaTC));
+  CHECK(hipMalloc(&quad, sizeof(int4) * G));
+  std::vector<double> rnd(size_t(mics) * NR * N2 * 2);
+  srand(1);
+  for (auto& v : rnd) v = rand() / double(RAND_MAX) - 0.5;
+  CHECK(hipMemcpy(SP, rnd.data(), rnd.size() * 8, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(b, rnd.data(), sizeof(cd) * N2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(hhat, rnd.data(), sizeof(cd) << LM, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(r1, rnd.data(), sizeof(cd) * N1, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(tws, rnd.data(), sizeof(cd) << LM, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(T, rnd.data(), sizeof(double) * h * nch * 2 * kPfaTC, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(Y, rnd.data(), sizeof(cd) * size_t(G < 32 ? G : 32) * n, hipMemcpyHostToDevice));
+  std::vector<int4> q(G);
+  for (int g = 0; g < G; ++g) {   // consecutive i<j pairs: (i, 2g+1), (i, 2g+2) share the first mic most of the time
+    const int i = g % 20;
+    q[g] = make_int4(i, 21 + (2 * g) % 40, i, 21 + (2 * g + 1) % 40);
+  }
+  CHECK(hipMemcpy(quad, q.data(), sizeof(int4) * G, hipMemcpyHostToDevice));
+  PfaRowsArgs a{SP, quad, Y, b, hhat, r1, tws, N1, N2, NR, G, 68, 1.0f / float(N1), nullptr};
+  const unsigned grid = unsigned(G) * NR, nblk = (N2 + 63) / 64;
+  printf("G = %d transforms (%d pairs)\n", G, 2 * G);
+  time_it("rows: product", 20, [&] { k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes)>>>(a); });
+  time_it("rows: compute only", 20, [&] { rows_var<LM, 1><<<dim3(grid), dim3(PfaLds<LM>::kLanes)>>>(a); });
+  time_it("rows: memory only", 20, [&] { rows_var<LM, 2><<<dim3(grid), dim3(PfaLds<LM>::kLanes)>>>(a); });
+  {   // phase clocks of every workgroup of one product launch
+    unsigned long long* st;
+    CHECK(hipMalloc(&st, sizeof(unsigned long long) * 8 * grid));
+    PfaRowsArgs as = a;
+    as.stamps = st;
+    k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes)>>>(as);
+    CHECK(hipDeviceSynchronize());
+    std::vector<unsigned long long> hs(size_t(8) * grid);
+    CHECK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
+    const char* names[5] = {"loads + whiten + stage 1", "forward middle", "seam", "inverse rest + store", "total"};
+    for (int ph = 0; ph < 5; ++ph) {
+      std::vector<double> d(grid);
+      for (unsigned w = 0; w < grid; ++w)
+        d[w] = ph < 4 ? double(hs[size_t(w) * 8 + ph + 1] - hs[size_t(w) * 8 + ph]) / 100.0 : double(hs[size_t(w) * 8 + 4] - hs[size_t(w) * 8]) / 100.0;
+      std::sort(d.begin(), d.end());
+      printf("  rows phase %-28s median %6.2f us  p90 %6.2f us\n", names[ph], d[grid / 2], d[grid * 9 / 10]);
+    }
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (unsigned w = 0; w < grid; ++w) { t0 = std::min(t0, hs[size_t(w) * 8]); t1 = std::max(t1, hs[size_t(w) * 8 + 4]); }
+    printf("  rows launch span %.1f us\n", double(t1 - t0) / 100.0);
+  }
+  const dim3 cg(unsigned(G) * nblk, 1);
+  time_it("cols: product", 20, [&] { k_pfa_cols<kPfaTC><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: variant unroll 1", 20, [&] { cols_var<kPfaTC, 0, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: variant unroll 2", 20, [&] { cols_var<kPfaTC, 0, 2><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: variant unroll 4", 20, [&] { cols_var<kPfaTC, 0, 4><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: no table loads, unroll 1", 20, [&] { cols_var<kPfaTC, 1, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: no table loads, unroll 4", 20, [&] { cols_var<kPfaTC, 1, 4><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: no Y loads, unroll 1", 20, [&] { cols_var<kPfaTC, 2, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  return 0;
+}
