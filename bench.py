@@ -54,6 +54,7 @@ def main() -> None:
     ap.add_argument("--chunk", type=int, default=0, help="transforms per launch group (0 = engine default)")
     ap.add_argument("--cpu-mics", type=int, default=24, help="mics of frame 0 in the CPU baseline / parity sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,13 +126,15 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     barrier()
-    eng.profile_begin()
+    if not args.no_kernel_events:
+        eng.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    eng.profile_end()
+    if not args.no_kernel_events:
+        eng.profile_end()
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)

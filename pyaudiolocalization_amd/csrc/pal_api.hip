@@ -454,14 +454,7 @@ int pal_profile_get(pal_handle h, const char* name, double* total_ms, int64_t* l
   return PAL_OK;
 }
 
-/* diagnostics: copy out the peak kernel's phase stamps of the last launch (PAL_PEAK_STAMPS=1), [count][8] */
-extern "C" int pal_debug_peak_stamps(pal_handle h, unsigned long long* out, int count) {
-  ENGINE(h);
-  if (!e->ws[10] || count < 1 || count > 8192) return e->fail(PAL_ERR_INVALID, "no stamps recorded");
-  PAL_TRY(e->check(hipStreamSynchronize(e->stream), "sync"));
-  PAL_TRY(e->check(hipStreamSynchronize(e->stream2), "sync"));
-  return e->check(hipMemcpy(out, e->ws[10], size_t(count) * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost), "stamps");
-}
+
 
 int pal_profile_entry(pal_handle h, int index, char* name, int cap, double* total_ms, int64_t* launches) {
   ENGINE(h);

@@ -1,18 +1,24 @@
-// peaks.hip - peak selection and correlation metrics, one PHAT row per 512-lane workgroup (gfx950).
+// peaks.hip - peak selection and correlation metrics of the PHAT rows (gfx950), three launches per group:
 //
-// Replaces utils.py:140-181 (threshold, scipy.signal.find_peaks(height, distance), the whole
-// fallback chain, window filter, top-num_peaks), utils.py:228-250 (compute_snr /
-// compute_peak_to_peak_ratio inputs) and np.max(corr) of main.py:223.
+//   k_peak_pivots  one workgroup per row: an 8192-point block sample gives the shifts of the one-pass variances
+//                  and two pivots that bracket the median of |corr| (4 sigma of the sample's rank error)
+//   k_peak_stream  the row (n doubles, 0.7 MB at 44.1 kHz x 1 s) is cut into segments of a few 2048-element
+//                  tiles; every 256-lane workgroup streams ONE segment with 16-byte loads, four in flight per
+//                  lane plus a register double buffer: max / first argmax, min, shifted sums for the SNR and
+//                  the 'adaptive' threshold, the highest local maximum, the count below the lower pivot, and
+//                  the values between the pivots (compacted in LDS, flushed to the row's global list with one
+//                  atomic per workgroup).  Small LDS, no inter-workgroup waits: bandwidth-bound, and light
+//                  enough to run beside the FFT passes of the next launch group.
+//   k_peak_finish  one workgroup per row: merges the segment results, SNR window, exact median by a rank search
+//                  inside the bracket list (radix select over the IEEE-754 bit pattern if the pivots missed or
+//                  the list overflowed), then scipy's find_peaks and the reference's fallback chain.
 //
-// The row (n doubles, 0.7 MB at 44.1 kHz x 1 s) is streamed ONCE with 16-byte loads, four in flight
-// per lane: max / first argmax, min, shifted sums for the SNR and the 'adaptive' threshold, the
-// highest local maximum, and - for the exact median of |corr| - the values that fall between two
-// pivots taken from an 8192-point block sample are compacted into LDS while everything below the
-// lower pivot is only counted.  The median is then an exact rank search inside LDS; if the pivots
-// missed (they bracket the median with >4 sigma of the sample's rank error) or LDS overflows, a
-// radix select over the IEEE-754 bit pattern re-reads the row (11-bit digits, LDS histograms).
-// The tiles of the pass are branch-free (guarded loads serialise on s_waitcnt); lane 0 / lane 63 of
-// every wavefront leave their outer element's peak test to a short edge pass.
+// Replaces utils.py:140-181 (threshold, scipy.signal.find_peaks(height, distance), the whole fallback chain,
+// window filter, top-num_peaks), utils.py:228-250 (compute_snr / compute_peak_to_peak_ratio inputs) and
+// np.max(corr) of main.py:223.
+//
+// The tiles of the stream are branch-free (guarded loads serialise on s_waitcnt); lane 0 / lane 63 of every
+// wavefront leave their outer element's peak test to a short edge pass.
 //
 // scipy's find_peaks is evaluated lazily and exactly instead of materialising peak lists:
 //   - a sample m is a peak iff it is the floor-midpoint of a plateau whose two outer neighbours
@@ -21,7 +27,7 @@
 //     then position) lies closer than `distance`; that recursion is resolved depth first from the
 //     candidate, with a memo, because chains of rising peaks are short   (_select_by_peak_distance)
 //   - candidates are visited in descending priority inside the lag window until num_peaks are kept.
-// Reductions: wavefront (64-lane) shuffles, then one LDS hop across the 8 wavefronts.
+// Reductions: wavefront (64-lane) shuffles, then one LDS hop across the wavefronts.
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -33,15 +39,30 @@ namespace pal {
 
 namespace {
 
-constexpr int kT = 512;           // lanes per row (1024 would cap the kernel at 128 VGPRs and spill)
-constexpr int kNW = kT / 64;      // wavefronts per row
-constexpr int kList = 16384;      // LDS capacity of the pivot bracket (doubles, 128 KiB)
-constexpr int kSample = 8192;     // strided sample that places the pivots
+constexpr int kT = 512;           // lanes of the pivot and finish kernels (one row per workgroup)
+constexpr int kNW = kT / 64;
+constexpr int kTS = 256;          // lanes of the stream kernel (one segment per workgroup)
+constexpr int kNWS = kTS / 64;
+constexpr int kList = 16384;      // capacity of a row's bracket list in global memory (doubles)
+constexpr int kLoc = 2048;        // LDS capacity of one segment's share of it
+constexpr int kSample = 8192;     // block sample that places the pivots
 constexpr int kBins = 2048;       // histogram bins (sample pivots, list search, radix digits)
 constexpr int kSmall = 1024;      // exact rank search capacity
 constexpr int kMemo = 1024;       // resolved peaks remembered per selection
 constexpr int kStack = 64;        // depth of the suppression recursion
 constexpr int kUnroll = 4;        // 16-byte loads in flight per lane
+constexpr int kTile = kTS * kUnroll;   // element pairs per tile of the stream
+
+struct RowPre {                          // k_peak_pivots -> the other two
+  double k0, ka;                         // ~ mean(x), ~ mean(|x|): shifts of the one-pass sums
+  double lo, hi;                         // pivots around the median of |x| (0 / inf when no median is needed)
+};
+
+struct Partial {                         // one segment's share of the streaming pass
+  double vmax, vmin, hb, s1, s2, a1, a2;
+  long long below;
+  int imax, imin, mb, pad;
+};
 
 struct PeakArgs {
   const double* corr;
@@ -49,22 +70,14 @@ struct PeakArgs {
   int n, n2;
   double fs, mult, med;   // med: NaN = no window
   int method, dist, num_peaks, snr_w;   // method: 0 median, 1 adaptive, < 0 metrics only
-  int splits;                            // workgroups per row (the last one to arrive finishes the row)
-  struct Partial* parts;                 // [rows][splits]
-  double* glist;                         // [rows][kList] bracket values of split rows
-  int* gcount;                           // [rows] fill of glist
-  int* arrive;                           // [rows] arrival tickets
-  unsigned long long* stamps;            // diagnostics only (PAL_PEAK_STAMPS=1): [rows][8] 100 MHz clock reads of lane 0
+  int splits, tiles_per_seg;             // segments per row, tiles per segment
+  RowPre* pre;                           // [rows]
+  Partial* parts;                        // [rows][splits]
+  double* glist;                         // [rows][kList] bracket values
+  int* gcount;                           // [rows] fill of glist (> kList: overflow, the finish kernel re-reads the row)
 };
 
-struct Partial {                         // one workgroup's share of the streaming pass
-  double vmax, vmin, hb, s1, s2, a1, a2;
-  long long below;
-  int imax, imin, mb, pad;
-};
-
-struct Shared {
-  double list[kList];
+struct Shared {                          // pivot and finish kernels
   unsigned hist[kBins];
   double small[kSmall];
   double red_d[kNW];
@@ -84,25 +97,34 @@ struct Shared {
   int bc_i[4];
 };
 
+struct StreamShared {                    // stream kernel
+  double list[kLoc];
+  double red_d[kNWS];
+  double many[kNWS * 8];
+  int red_i[kNWS];
+  int count;
+  int bc_i;
+};
+
 __device__ __forceinline__ bool higher(double h1, int m1, double h2, int m2) {   // priority(h1,m1) > priority(h2,m2)
   return h1 > h2 || (h1 == h2 && m1 > m2);
 }
 
 __device__ double bsum(double v, Shared& s, int tid) { return block_sum<kNW>(v, s.red_d, tid); }
-template <int N> __device__ void bsum_many(double (&v)[N], Shared& s, int tid) {   // N sums, one barrier pair
+template <int N, int NW> __device__ void bsum_many(double (&v)[N], double* many, int tid) {   // N sums, one barrier pair
 #pragma unroll
   for (int q = 0; q < N; ++q)
     for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_down(v[q], o, 64);
   __syncthreads();
   if ((tid & 63) == 0) {
 #pragma unroll
-    for (int q = 0; q < N; ++q) s.many[(tid >> 6) * N + q] = v[q];
+    for (int q = 0; q < N; ++q) many[(tid >> 6) * N + q] = v[q];
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < N; ++q) {
     double r = 0;
-    for (int k = 0; k < kNW; ++k) r += s.many[k * N + q];
+    for (int k = 0; k < NW; ++k) r += many[k * N + q];
     v[q] = r;
   }
 }
@@ -175,17 +197,18 @@ __device__ __forceinline__ bool peak_mid(const double* c, int n, int m, double& 
   return true;
 }
 
-// ---- exact rank inside an LDS list whose values lie in [lo, hi] ----
+// ---- exact rank inside the row's bracket list (global memory, L2-resident) whose values lie in [lo, hi] ----
 // linear bins spread the bracket over the histogram; the winning bin (a handful of values) is ranked by counting.
 // returns false when that bin is too crowded for the exact search (caller falls back to the radix select)
-__device__ bool list_select(Shared& s, int tid, int cnt, unsigned rank, double lo, double hi, double& out) {
+__device__ bool list_select(Shared& s, int tid, const double* __restrict__ list, int cnt, unsigned rank, double lo, double hi,
+                            double& out) {
   for (int k = tid; k < kBins; k += kT) s.hist[k] = 0;
   if (tid == 0) s.count2 = 0;
   __syncthreads();
   const double span = hi - lo;
   const double inv = (span > 0 && isfinite(span)) ? double(kBins - 1) / span : 0.0;
   for (int e = tid; e < cnt; e += kT) {
-    int b = int((s.list[e] - lo) * inv);
+    int b = int((list[e] - lo) * inv);
     b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
     atomicAdd(&s.hist[b], 1u);
   }
@@ -198,7 +221,7 @@ __device__ bool list_select(Shared& s, int tid, int cnt, unsigned rank, double l
     bool hit = false;
     double v = 0;
     if (e < cnt) {
-      v = s.list[e];
+      v = list[e];
       int b = int((v - lo) * inv);
       b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
       hit = unsigned(b) == bin;
@@ -449,24 +472,15 @@ __device__ __forceinline__ void peak_test(Stream& t, const double* c, int n, int
   if (t.mb < 0 || higher(x, m, t.hb, t.mb)) { t.hb = x; t.mb = m; t.dirty = 1; }
 }
 
-__global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table, int32_t* ksel_multi, int* status) {
+// ------------------------------------------------------------------ 1. pivots
+// block sample (16 coalesced runs of 512 samples spread over the row): shifts for the one-pass variances and
+// the pivots that bracket the median
+__global__ __launch_bounds__(kT) void k_peak_pivots(PeakArgs a) {
   __shared__ Shared s;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int S = a.splits;
-  const int row = blockIdx.x / S, seg = blockIdx.x % S;
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x;
   const double* c = a.corr + size_t(row) * a.stride;
   const int n = a.n;
-  const bool want_median = a.method == 0;
-  int stamp_at = 0;
-  unsigned long long* const stamps = a.stamps;   // (a local: capturing the argument struct by reference would push it,
-  auto stamp = [&]() {                           //  and every pointer in it, through private memory)
-    if (stamps && tid == 0 && stamp_at < 8) stamps[size_t(blockIdx.x) * 8 + stamp_at] = __builtin_amdgcn_s_memrealtime();
-    ++stamp_at;   // never set in production runs; values go to a buffer nothing else reads
-  };
-  stamp();
-
-  // ---- block sample (16 coalesced runs of kT samples spread over the row): shifts for the one-pass
-  //      variances and the pivots that bracket the median ----
   constexpr int kRuns = kSample / kT;
   const int ns = n < kSample ? n : kSample;
   double sv[kRuns];
@@ -481,15 +495,15 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
   }
   const double k0 = bsum(ssum, s, tid) / double(ns);          // ~ mean(x)
   const double ka = bsum(sabs, s, tid) / double(ns);          // ~ mean(|x|)
-  const unsigned r1 = unsigned((n - 1) / 2), r2 = unsigned(n / 2);   // ranks of the median's one or two order statistics
   double lo = 0, hi = INFINITY;
-  if (want_median) {
+  if (a.method == 0) {
+    const unsigned r1 = unsigned((n - 1) / 2), r2 = unsigned(n / 2);   // ranks of the median's one or two order statistics
     for (int k = tid; k < kBins; k += kT) s.hist[k] = 0;
     __syncthreads();
     const double top = ka > 0 ? 4.0 * ka : 1.0;               // median <= 2 mean for non-negative data
     const double inv = double(kBins - 1) / top;
 #pragma unroll
-    for (int q = 0; q < kSample / kT; ++q) {
+    for (int q = 0; q < kRuns; ++q) {
       if (tid + q * kT < ns) {
         int b = int(fabs(sv[q]) * inv);
         atomicAdd(&s.hist[b < kBins - 1 ? b : kBins - 1], 1u);
@@ -508,11 +522,28 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
     if (slo == 0) lo = 0;
     if (shi == unsigned(ns - 1)) hi = INFINITY;
   }
+  if (tid == 0) {
+    RowPre pre;
+    pre.k0 = k0; pre.ka = ka; pre.lo = lo; pre.hi = hi;
+    a.pre[row] = pre;
+  }
+}
+
+// ------------------------------------------------------------------ 2. stream
+__global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
+  __shared__ StreamShared s;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int S = a.splits;
+  const int row = blockIdx.x / S, seg = blockIdx.x % S;
+  const double* c = a.corr + size_t(row) * a.stride;
+  const int n = a.n;
+  const bool want_median = a.method == 0;
+  const RowPre pre = a.pre[row];
+  const double k0 = pre.k0, ka = pre.ka, lo = pre.lo, hi = pre.hi;
   if (tid == 0) s.count = 0;
   __syncthreads();
-  stamp();
 
-  // ---- the single pass: branch-free tiles of kUnroll 16-byte loads per lane, then a short guarded tail ----
+  // ---- branch-free tiles of kUnroll 16-byte loads per lane, then a short guarded tail ----
   Stream t;
   t.vmax = t.vmin = t.hb = 0;
   t.imax = t.imin = t.mb = -1;
@@ -523,11 +554,10 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
   t.dirty = 0;
   const bool aligned = (reinterpret_cast<size_t>(c) & 15) == 0;
   const int npair = (n + 1) / 2;
-  constexpr int kTile = kT * kUnroll;                          // element pairs per tile
   // this workgroup's share: a whole number of tiles, so segment borders fall on multiples of 128 elements
-  const int tiles_per_seg = ((npair + kTile - 1) / kTile + S - 1) / S;
-  const int p_lo = seg * tiles_per_seg * kTile < npair ? seg * tiles_per_seg * kTile : npair;
-  const int p_hi = p_lo + tiles_per_seg * kTile < npair ? p_lo + tiles_per_seg * kTile : npair;
+  const int per_seg = a.tiles_per_seg * kTile;
+  const int p_lo = seg * per_seg < npair ? seg * per_seg : npair;
+  const int p_hi = p_lo + per_seg < npair ? p_lo + per_seg : npair;
   const int both = p_hi < n / 2 ? p_hi : n / 2;                // pairs below `both` have two valid elements
   const int full = p_lo + (both > p_lo ? (both - p_lo) / kTile * kTile : 0);   // end of the branch-free tiles
   // Element e = 2p (+1) of pair p; lane = p % 64.  Neighbours come from the adjacent lanes; the first element
@@ -540,7 +570,7 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
     int run = 0;
 #pragma unroll
     for (int k = 0; k < kUnroll; ++k) {
-      const int e0 = 2 * (pair0 + k * kT);
+      const int e0 = 2 * (pair0 + k * kTS);
       const bool va = full_tile || e0 < n, vb = full_tile || e0 + 1 < n;
       const double left = __shfl_up(xb[k], 1, 64);
       const double right = __shfl_down(xa[k], 1, 64);
@@ -569,24 +599,23 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
       base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) {
-        if (off[2 * k] >= 0 && base + off[2 * k] < kList) s.list[base + off[2 * k]] = fabs(xa[k]);
-        if (off[2 * k + 1] >= 0 && base + off[2 * k + 1] < kList) s.list[base + off[2 * k + 1]] = fabs(xb[k]);
+        if (off[2 * k] >= 0 && base + off[2 * k] < kLoc) s.list[base + off[2 * k]] = fabs(xa[k]);
+        if (off[2 * k + 1] >= 0 && base + off[2 * k + 1] < kLoc) s.list[base + off[2 * k + 1]] = fabs(xb[k]);
       }
     }
     refresh_filters(t);
   };
-  // register double buffer: the next tile's loads are in flight while this one is consumed (one 157 KB-LDS
-  // workgroup per CU leaves only 8 wavefronts to hide the latency, so the loop must do it itself)
+  // register double buffer: the next tile's loads are in flight while this one is consumed
   if (aligned) {
     double2 cur[kUnroll], nxt[kUnroll];
     if (p_lo < full) {
 #pragma unroll
-      for (int k = 0; k < kUnroll; ++k) cur[k] = *reinterpret_cast<const double2*>(c + 2 * (p_lo + k * kT + tid));
+      for (int k = 0; k < kUnroll; ++k) cur[k] = *reinterpret_cast<const double2*>(c + 2 * (p_lo + k * kTS + tid));
     }
     for (int base = p_lo; base < full; base += kTile) {
       const int ahead = base + kTile < full ? base + kTile : base;    // last round re-reads its own tile: no branch
 #pragma unroll
-      for (int k = 0; k < kUnroll; ++k) nxt[k] = *reinterpret_cast<const double2*>(c + 2 * (ahead + k * kT + tid));
+      for (int k = 0; k < kUnroll; ++k) nxt[k] = *reinterpret_cast<const double2*>(c + 2 * (ahead + k * kTS + tid));
       double xa[kUnroll], xb[kUnroll];
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) { xa[k] = cur[k].x; xb[k] = cur[k].y; }
@@ -599,8 +628,8 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
       double xa[kUnroll], xb[kUnroll];
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) {
-        xa[k] = c[2 * (base + k * kT + tid)];
-        xb[k] = c[2 * (base + k * kT + tid) + 1];
+        xa[k] = c[2 * (base + k * kTS + tid)];
+        xb[k] = c[2 * (base + k * kTS + tid) + 1];
       }
       consume_tile(xa, xb, base + tid, true);
     }
@@ -609,83 +638,73 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
     double xa[kUnroll], xb[kUnroll];
 #pragma unroll
     for (int k = 0; k < kUnroll; ++k) {
-      const int e0 = 2 * (full + k * kT + tid);
+      const int e0 = 2 * (full + k * kTS + tid);
       xa[k] = e0 < n ? c[e0] : 0.0;
       xb[k] = e0 + 1 < n ? c[e0 + 1] : 0.0;
     }
     consume_tile(xa, xb, full + tid, false);
   }
-  for (int j = tid; 2 * p_lo + 64 * j < 2 * p_hi; j += kT) {   // edge pass: e = 128 q and e = 128 q + 127
+  for (int j = tid; 2 * p_lo + 64 * j < 2 * p_hi; j += kTS) {  // edge pass: e = 128 q and e = 128 q + 127
     const int e = 2 * p_lo + (j >> 1) * 128 + ((j & 1) ? 127 : 0);
     if (e >= 1 && e <= n - 2 && e < 2 * p_hi) peak_test(t, c, n, e, c[e - 1], c[e], c[e + 1]);
   }
-  stamp();
   double vmax = t.vmax, vmin = t.vmin, hb = t.hb;
   int imax = t.imax, imin = t.imin, mb = t.mb;
-  barg<0>(vmax, imax, s, tid);
-  barg<1>(vmin, imin, s, tid);
-  barg<2>(hb, mb, s, tid);
+  block_arg<0, kNWS>(vmax, imax, s.red_d, s.red_i, tid);
+  block_arg<1, kNWS>(vmin, imin, s.red_d, s.red_i, tid);
+  block_arg<2, kNWS>(hb, mb, s.red_d, s.red_i, tid);
   double sums[5] = {t.s1, t.s2, t.a1, t.a2, double(t.below)};   // one barrier pair for all five (counts < 2^31 are exact in fp64)
-  bsum_many<5>(sums, s, tid);
-  double s1 = sums[0], s2 = sums[1], a1 = sums[2], a2 = sums[3];
-  long long below = (long long)sums[4];
-  int cnt = s.count;
+  bsum_many<5, kNWS>(sums, s.many, tid);
 
-  if (S > 1) {
-    // ---- hand-off: every share publishes its partial result and bracket values; the last workgroup to arrive
-    //      (agent-scope release / acquire around one atomic ticket, cdna_hip_programming.md guideline 16) finishes the row
-    if (want_median) {
-      if (tid == 0) s.bc_i[3] = atomicAdd(&a.gcount[row], cnt);
-      __syncthreads();
-      const int at = s.bc_i[3];
-      double* dst = a.glist + size_t(row) * kList;
-      if (cnt <= kList && at >= 0)
-        for (int k = tid; k < cnt; k += kT)
-          if (at + k < kList) dst[at + k] = s.list[k];
-    }
-    if (tid == 0) {
-      Partial pt;
-      pt.vmax = vmax; pt.vmin = vmin; pt.hb = hb; pt.s1 = s1; pt.s2 = s2; pt.a1 = a1; pt.a2 = a2;
-      pt.below = below; pt.imax = imax; pt.imin = imin; pt.mb = mb; pt.pad = 0;
-      a.parts[size_t(row) * S + seg] = pt;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- publish: the segment's bracket values join the row's list (one global atomic), its statistics its slot ----
+  if (want_median) {
+    const int cnt = s.count;
+    if (tid == 0) s.bc_i = atomicAdd(&a.gcount[row], cnt <= kLoc ? cnt : kList + 1);   // LDS overflow poisons the list
     __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      s.bc_i[3] = atomicAdd(&a.arrive[row], 1);
-    }
-    __syncthreads();
-    if (s.bc_i[3] != S - 1) return;                            // workgroup-uniform: not the last share
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    imax = imin = mb = -1;
-    vmax = vmin = hb = s1 = s2 = a1 = a2 = 0;
-    below = 0;
-    for (int q = 0; q < S; ++q) {
-      const Partial pt = a.parts[size_t(row) * S + q];
-      if (pt.imax >= 0 && (imax < 0 || arg_better<0>(pt.vmax, pt.imax, vmax, imax))) { vmax = pt.vmax; imax = pt.imax; }
-      if (pt.imin >= 0 && (imin < 0 || arg_better<1>(pt.vmin, pt.imin, vmin, imin))) { vmin = pt.vmin; imin = pt.imin; }
-      if (pt.mb >= 0 && (mb < 0 || higher(pt.hb, pt.mb, hb, mb))) { hb = pt.hb; mb = pt.mb; }
-      s1 += pt.s1; s2 += pt.s2; a1 += pt.a1; a2 += pt.a2;
-      below += pt.below;
-    }
-    if (want_median) {
-      cnt = a.gcount[row];
-      const double* src = a.glist + size_t(row) * kList;
-      for (int k = tid; k < cnt && k < kList; k += kT) s.list[k] = src[k];
-    }
-    __syncthreads();
+    const int at = s.bc_i;
+    double* dst = a.glist + size_t(row) * kList;
+    if (cnt <= kLoc && at >= 0 && at + cnt <= kList)
+      for (int k = tid; k < cnt; k += kTS) dst[at + k] = s.list[k];
   }
+  if (tid == 0) {
+    Partial pt;
+    pt.vmax = vmax; pt.vmin = vmin; pt.hb = hb; pt.s1 = sums[0]; pt.s2 = sums[1]; pt.a1 = sums[2]; pt.a2 = sums[3];
+    pt.below = (long long)sums[4]; pt.imax = imax; pt.imin = imin; pt.mb = mb; pt.pad = 0;
+    a.parts[size_t(row) * S + seg] = pt;
+  }
+}
+
+// ------------------------------------------------------------------ 3. finish
+__global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record* table, int32_t* ksel_multi, int* status) {
+  __shared__ Shared s;
+  const int tid = threadIdx.x;
+  const int S = a.splits;
+  const int row = blockIdx.x;
+  const double* c = a.corr + size_t(row) * a.stride;
+  const int n = a.n;
+  const bool want_median = a.method == 0;
+  const RowPre pre = a.pre[row];
+  const double k0 = pre.k0, ka = pre.ka, lo = pre.lo, hi = pre.hi;
+  const unsigned r1 = unsigned((n - 1) / 2), r2 = unsigned(n / 2);   // ranks of the median's one or two order statistics
+
+  // ---- merge the segments (every lane the same loop: no broadcast needed) ----
+  int imax = -1, imin = -1, mb = -1;
+  double vmax = 0, vmin = 0, hb = 0, s1 = 0, s2 = 0, a1 = 0, a2 = 0;
+  long long below = 0;
+  for (int q = 0; q < S; ++q) {
+    const Partial pt = a.parts[size_t(row) * S + q];
+    if (pt.imax >= 0 && (imax < 0 || arg_better<0>(pt.vmax, pt.imax, vmax, imax))) { vmax = pt.vmax; imax = pt.imax; }
+    if (pt.imin >= 0 && (imin < 0 || arg_better<1>(pt.vmin, pt.imin, vmin, imin))) { vmin = pt.vmin; imin = pt.imin; }
+    if (pt.mb >= 0 && (mb < 0 || higher(pt.hb, pt.mb, hb, mb))) { hb = pt.hb; mb = pt.mb; }
+    s1 += pt.s1; s2 += pt.s2; a1 += pt.a1; a2 += pt.a2;
+    below += pt.below;
+  }
+  const int cnt = want_median ? a.gcount[row] : 0;
+  const double* list = a.glist + size_t(row) * kList;
   const double mean_abs = ka + a1 / double(n);                 // np.mean(np.abs(corr)) (utils.py:155)
   if (imax < 0 || imax >= n) imax = 0;                         // all-NaN row (and a guard for every index used below)
   if (mb >= n) mb = -1;
 
-  stamp();
   // ---- SNR (utils.py:238-250): totals minus the window around the maximum ----
   const int wlo_s = imax - a.snr_w > 0 ? imax - a.snr_w : 0;
   const int whi_s = imax + a.snr_w < n ? imax + a.snr_w : n;
@@ -727,15 +746,14 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
     return;
   }
 
-  stamp();
   // ---- primary threshold (utils.py:144-149) ----
   double thr1;
   if (want_median) {
     double m0 = 0, m1 = 0;
-    bool ok = cnt <= kList && (long long)r1 >= below && (long long)r2 < below + cnt;
-    if (ok) ok = list_select(s, tid, cnt, unsigned(r1 - below), lo, hi, m0);
-    if (ok) { m1 = m0; if (r2 != r1) ok = list_select(s, tid, cnt, unsigned(r2 - below), lo, hi, m1); }
-    if (!ok) {                                                 // pivots missed or LDS overflow: exact radix select
+    bool ok = cnt >= 0 && cnt <= kList && (long long)r1 >= below && (long long)r2 < below + cnt;
+    if (ok) ok = list_select(s, tid, list, cnt, unsigned(r1 - below), lo, hi, m0);
+    if (ok) { m1 = m0; if (r2 != r1) ok = list_select(s, tid, list, cnt, unsigned(r2 - below), lo, hi, m1); }
+    if (!ok) {                                                 // pivots missed or a list overflowed: exact radix select
       m0 = radix_select(c, n, tid, s, r1);
       m1 = r2 != r1 ? radix_select(c, n, tid, s, r2) : m0;
     }
@@ -746,7 +764,6 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
     thr1 = a.mult * (mean_abs + sqrt(va));                     // mean + std of |corr| (utils.py:147)
   }
 
-  stamp();
   // ---- fallback chain (utils.py:152-179) ----
   int branch = 0;
   int sel[PAL_MAX_PEAKS];
@@ -782,7 +799,6 @@ __global__ __launch_bounds__(kT) void k_peaks(PeakArgs a, pal_pair_record* table
     }
   }
   if (argmax_fallback || overflow) { sel[0] = imax; selh[0] = vmax; count = 1; }
-  stamp();
 
   if (tid == 0) {
     pal_pair_record r;
@@ -826,34 +842,39 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
   a.method = prm.threshold_method; a.dist = prm.peak_distance; a.num_peaks = prm.num_peaks;
   const int w = int(0.01 * double(n));                       // utils.py:244
   a.snr_w = w > 1 ? w : 1;
-  // few rows: split each over several workgroups so that the launch covers the chip (one 157 KB-LDS workgroup per CU)
-  int splits = 256 / rows;
-  splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
-  a.splits = splits;
-  a.parts = nullptr; a.glist = nullptr; a.gcount = nullptr; a.arrive = nullptr;
-  a.stamps = nullptr;
-  if (getenv("PAL_PEAK_STAMPS")) {               // diagnostic runs only: phase clocks of every workgroup of this launch
-    void* st = nullptr;
-    PAL_TRY(scratch(10, size_t(8192) * 8 * sizeof(unsigned long long), &st));
-    a.stamps = static_cast<unsigned long long*>(st);
+  // segments: about 1024 workgroups per launch (four resident per CU, all in flight at once), so that a workgroup
+  // streams as many tiles as possible behind one set of fixed costs (row parameters, reductions, publish)
+  const int ntiles = ((n + 1) / 2 + kTile - 1) / kTile;
+  int want = (1024 + rows - 1) / rows;
+  want = want < 1 ? 1 : (want > ntiles ? ntiles : want);
+  a.tiles_per_seg = (ntiles + want - 1) / want;
+  a.splits = (ntiles + a.tiles_per_seg - 1) / a.tiles_per_seg;
+  // per-stream scratch: [gcount | pre | parts | glist]; the list fills are zeroed in front of every launch
+  size_t off_pre = (size_t(rows) * sizeof(int) + 127) & ~size_t(127);
+  size_t off_parts = (off_pre + size_t(rows) * sizeof(RowPre) + 127) & ~size_t(127);
+  size_t off_list = (off_parts + size_t(rows) * a.splits * sizeof(Partial) + 127) & ~size_t(127);
+  const size_t total = off_list + (a.method == 0 ? size_t(rows) * kList * sizeof(double) : 0);
+  void* sp = nullptr;
+  PAL_TRY(scratch(on == stream2 ? 9 : 8, total, &sp));
+  char* base = static_cast<char*>(sp);
+  a.gcount = reinterpret_cast<int*>(base);
+  a.pre = reinterpret_cast<RowPre*>(base + off_pre);
+  a.parts = reinterpret_cast<Partial*>(base + off_parts);
+  a.glist = reinterpret_cast<double*>(base + off_list);
+  PAL_HIP(hipMemsetAsync(a.gcount, 0, size_t(rows) * sizeof(int), on));
+  {
+    ProfScope ps(this, "k_peak_pivots", on);
+    k_peak_pivots<<<dim3(rows), dim3(kT), 0, on>>>(a);
+    PAL_HIP(hipGetLastError());
   }
-  if (splits > 1) {
-    const size_t per_slot = size_t(rows) * (2 * sizeof(int) + size_t(splits) * sizeof(Partial) + size_t(kList) * sizeof(double)) + 256;
-    void* sp = nullptr;
-    PAL_TRY(scratch(on == stream2 ? 9 : 8, per_slot, &sp));
-    char* base = static_cast<char*>(sp);
-    // tickets and list fills are zeroed by a memset node in front of every launch (the layout moves with `rows`)
-    PAL_HIP(hipMemsetAsync(base, 0, size_t(2 * rows) * sizeof(int), on));
-    a.arrive = reinterpret_cast<int*>(base);
-    a.gcount = a.arrive + rows;
-    size_t off = (size_t(2 * rows) * sizeof(int) + 127) & ~size_t(127);
-    a.parts = reinterpret_cast<Partial*>(base + off);
-    off = (off + size_t(rows) * splits * sizeof(Partial) + 127) & ~size_t(127);
-    a.glist = reinterpret_cast<double*>(base + off);
+  {
+    ProfScope ps(this, "k_peak_stream", on);
+    k_peak_stream<<<dim3(unsigned(rows) * unsigned(a.splits)), dim3(kTS), 0, on>>>(a);
+    PAL_HIP(hipGetLastError());
   }
-  ProfScope ps(this, metrics_only ? "k_peaks(metrics)" : "k_peaks", on);
-  k_peaks<<<dim3(rows * splits), dim3(kT), 0, on>>>(a, table, ksel_multi, status);
-  return check(hipGetLastError(), "k_peaks");
+  ProfScope ps(this, metrics_only ? "k_peak_finish(metrics)" : "k_peak_finish", on);
+  k_peak_finish<<<dim3(rows), dim3(kT), 0, on>>>(a, table, ksel_multi, status);
+  return check(hipGetLastError(), "k_peak_finish");
 }
 
 }  // namespace pal

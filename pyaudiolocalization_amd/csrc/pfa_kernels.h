@@ -118,14 +118,15 @@ __device__ __forceinline__ double swap_halves(double v, bool upper) {
 //      run on the same sixteen registers (the last stage's outputs k + P r are exactly the inputs
 //      i + (M/16) r' of a first-stage butterfly), which saves one LDS round trip and two barriers.
 //   4. the remaining inverse stages; the last one hands Y to global memory.
-template <int LM>
+template <int LM, bool TWG = false>   // TWG: twiddles straight from global memory (L1-resident table) instead of an LDS copy
 __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) {
   using L = PfaLds<LM>;
   constexpr int M = L::kM, NB = M / 16;
   constexpr bool CT = L::kCompact;
   static_assert(stage_log2r(LM, 0) == 4, "the hand-mapped stages assume a radix-16 first stage");
   __shared__ cd data[2 * M];
-  __shared__ cd tw[L::kTw];
+  __shared__ cd tw_lds[TWG ? 1 : L::kTw];
+  const cd* const tw = TWG ? a.tws : tw_lds;
   const int tid = threadIdx.x;
   const int g = blockIdx.x % a.G, k1 = blockIdx.x / a.G;
   unsigned long long* const stamps = a.stamps;
@@ -137,8 +138,8 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
   stamp();
   // the twiddle rows travel global -> registers -> LDS; their loads are issued first and land while the pair
   // table and the spectrum rows are being fetched
-  constexpr int kTwPer = (L::kTw + L::kLanes - 1) / L::kLanes;
-  cd twr[kTwPer];
+  constexpr int kTwPer = TWG ? 0 : (L::kTw + L::kLanes - 1) / L::kLanes;
+  cd twr[kTwPer + 1];
 #pragma unroll
   for (int q = 0; q < kTwPer; ++q) {
     const int idx = tid + q * L::kLanes;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
 #pragma unroll
     for (int q = 0; q < kTwPer; ++q) {
       const int idx = tid + q * L::kLanes;
-      if (idx < L::kTw) tw[idx] = twr[q];
+      if (idx < L::kTw) tw_lds[idx] = twr[q];
     }
     cd mine[4], recv[4];
 #pragma unroll
@@ -235,7 +236,9 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
 // imaginary parts) and by chunk of kPfaTC output indices t; with E_j = Y_j + Y_{N1-j}, O_j = Y_j - Y_{N1-j}:
 //   p:  c[t] = Re Y_0 + sum_j cos(j t) Re E_j - sum_j sin(j t) Im O_j,   c[N1-t] = the same with + sin
 //   q:  c[t] = Im Y_0 + sum_j cos(j t) Im E_j + sum_j sin(j t) Re O_j,   c[N1-t] = the same with - sin
-// The cos / sin rows are wave-uniform: T[(j-1)][chunk][cos | sin][tt] is read through scalar loads.
+// The cos / sin rows are wave-uniform: T[(j-1)][chunk][cos | sin][tt] is read through scalar loads and feeds
+// v_fmac_f64 as a scalar operand.  The rows of Y for step j+1 are loaded before the FMAs of step j (the pass is
+// bound by memory latency, not arithmetic).
 template <int TC>
 __global__ __launch_bounds__(256) void k_pfa_cols(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
                                                   int N1, int N2, int G, int nch, const double* __restrict__ T) {
@@ -254,8 +257,11 @@ __global__ __launch_bounds__(256) void k_pfa_cols(const cd* __restrict__ Y, doub
   double sumE = 0.0;
   const double* Tj = T + size_t(ch) * 2 * TC;
   const size_t tstep = size_t(nch) * 2 * TC;
+  const cd y0 = Yg[0];
+  cd yj = Yg[size_t(h > 0 ? 1 : 0) * N2], ym = Yg[size_t(h > 0 ? N1 - 1 : 0) * N2];
   for (int j = 1; j <= h; ++j, Tj += tstep) {
-    const cd yj = Yg[size_t(j) * N2], ym = Yg[size_t(N1 - j) * N2];
+    const int jn = j < h ? j + 1 : j;                         // the last step re-reads its own rows: no branch
+    const cd nj = Yg[size_t(jn) * N2], nm = Yg[size_t(N1 - jn) * N2];
     const double a = role ? yj.y + ym.y : yj.x + ym.x;
     const double b = role ? yj.x - ym.x : yj.y - ym.y;
     sumE += a;
@@ -264,8 +270,9 @@ __global__ __launch_bounds__(256) void k_pfa_cols(const cd* __restrict__ Y, doub
       accC[tt] = __builtin_fma(Tj[tt], a, accC[tt]);
       accS[tt] = __builtin_fma(Tj[TC + tt], b, accS[tt]);
     }
+    yj = nj;
+    ym = nm;
   }
-  const cd y0 = Yg[0];
   const double base = role ? y0.y : y0.x;
   if (!live) return;
   double* out = corr + size_t(2 * g + role) * stride + m2;

@@ -342,7 +342,7 @@ def test_profile_counters_and_plan(engine):
     engine.profile_end()
     ent = engine.profile_entries()
     assert any(k.startswith("k_rows<") and v[1] > 0 for k, v in ent.items()), ent
-    assert ent["k_peaks"][1] >= 1
+    assert ent["k_peak_stream"][1] >= 1 and ent["k_peak_finish"][1] >= 1
 
 
 def test_rccl_single_rank_gather(engine):

@@ -147,34 +147,6 @@ for name, fn in (("peaksvar", peaksvar), ("phat", phat), ("select", select), ("a
         section(name, fn)
 
 
-def stamps():
-    """Phase clocks of k_peaks (diagnostic build path, PAL_PEAK_STAMPS=1)."""
-    import ctypes as C
-    from pyaudiolocalization_amd import make_params, RECORD, _ffi
-    from pyaudiolocalization_amd.synthetic import metric_frames
-    os.environ["PAL_PEAK_STAMPS"] = "1"
-    os.environ["PAL_OVERLAP"] = "0"
-    e2 = Engine(0)
-    frames = metric_frames(1, 64)
-    d_f = e2.alloc(frames.nbytes); e2.upload(d_f, frames)
-    d_t = e2.alloc(2016 * RECORD.itemsize)
-    for med in (0.05, None):
-        prm = make_params(44100, 1, "median", 1.0, med)
-        for _ in range(2):
-            e2.gcc_phat_all_pairs_dev(d_f, 1, 64, 44100, prm, d_t)
-        e2.synchronize()
-        lib = _ffi.load()
-        buf = np.zeros((224, 8), dtype=np.uint64)       # last launch of a frame: 2016 - 7*256 = 224 rows, one workgroup each
-        fn = lib.pal_debug_peak_stamps
-        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        rc = fn(e2._h, buf.ctypes.data, 224)
-        d = np.diff(buf.astype(np.int64), axis=1) / 100.0   # microseconds (100 MHz)
-        names = ["sample+pivots", "stream pass", "reductions(+handoff)", "snr window", "median select", "selection"]
-        print(f"  window={med}: rc={rc} median microseconds per phase:", {n: round(float(np.median(d[:, k])), 1) for k, n in enumerate(names)},
-              "total", round(float(np.median(buf[:, 6].astype(np.int64) - buf[:, 0].astype(np.int64))) / 100.0, 1))
-    os.environ.pop("PAL_PEAK_STAMPS")
-
-
 def pfa():
     """Prime-factor route against the four-step route and the oracle, per length."""
     os.environ["PAL_PFA"] = "0"
@@ -198,5 +170,3 @@ def pfa():
 if "pfa" in sys.argv[1:]:
     section("pfa", pfa)
 
-if "stamps" in sys.argv[1:]:
-    section("stamps", stamps)

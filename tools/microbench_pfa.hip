@@ -77,6 +77,68 @@ __global__ __launch_bounds__(256) void cols_var(const cd* __restrict__ Y, double
   }
 }
 
+// ---- column pass, register version with a software pipeline: loads run D iterations ahead of the FMAs
+template <int TC, int D>
+__global__ __launch_bounds__(256) void cols_pipe(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
+                                                 int N1, int N2, int G, int nch, const double* __restrict__ T) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+  const int role = wave & 1, ch = int(blockIdx.y) * 2 + (wave >> 1);
+  if (ch >= nch) return;
+  const int g = blockIdx.x % G, cb = blockIdx.x / G;
+  const int m2 = cb * 64 + lane;
+  const bool live = m2 < N2;
+  const cd* Yg = Y + size_t(g) * N1 * N2 + (live ? m2 : N2 - 1);
+  const int h = (N1 - 1) / 2;
+  double accC[TC], accS[TC];
+#pragma unroll
+  for (int tt = 0; tt < TC; ++tt) accC[tt] = accS[tt] = 0.0;
+  double sumE = 0.0;
+  const double* Tj = T + size_t(ch) * 2 * TC;
+  const size_t tstep = size_t(nch) * 2 * TC;
+  constexpr int RING = D + 1;
+  cd yj[RING], ym[RING];
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    const int j = 1 + u <= h ? 1 + u : h;
+    yj[u] = Yg[size_t(j) * N2]; ym[u] = Yg[size_t(N1 - j) * N2];
+  }
+  for (int j0 = 1; j0 <= h; j0 += RING) {
+#pragma unroll
+    for (int u = 0; u < RING; ++u) {
+      const int j = j0 + u;
+      const int jn = j + D <= h ? j + D : h;
+      yj[(u + D) % RING] = Yg[size_t(jn) * N2];
+      ym[(u + D) % RING] = Yg[size_t(N1 - jn) * N2];
+      if (j <= h) {
+        const double a = role ? yj[u].y + ym[u].y : yj[u].x + ym[u].x;
+        const double b = role ? yj[u].x - ym[u].x : yj[u].y - ym[u].y;
+        sumE += a;
+#pragma unroll
+        for (int tt = 0; tt < TC; ++tt) {
+          accC[tt] = __builtin_fma(Tj[tt], a, accC[tt]);
+          accS[tt] = __builtin_fma(Tj[TC + tt], b, accS[tt]);
+        }
+        Tj += tstep;
+      }
+    }
+  }
+  const cd y0 = Yg[0];
+  const double base = role ? y0.y : y0.x;
+  if (!live) return;
+  double* out = corr + size_t(2 * g + role) * stride + m2;
+  if (ch == 0) out[0] = base + sumE;
+#pragma unroll
+  for (int tt = 0; tt < TC; ++tt) {
+    const int t = ch * TC + tt + 1;
+    if (t <= h) {
+      const double s = role ? accS[tt] : -accS[tt];
+      out[size_t(N2) * t] = base + accC[tt] + s;
+      out[size_t(N2) * (N1 - t)] = base + accC[tt] - s;
+    }
+  }
+}
+
 // ---- row pass variants
 template <int LM> struct ConstIn {
   static constexpr bool kLds = false;
@@ -155,14 +217,14 @@ int main(int argc, char** argv) {
   double *corr, *T;
   int4* quad;
   CHECK(hipMalloc(&SP, sizeof(cd) * mics * NR * N2));
-  CHECK(hipMalloc(&Y, sizeof(cd) * size_t(G) * n));
+  CHECK(hipMalloc(&Y, sizeof(cd) * size_t(G) * (n + 128)));
   CHECK(hipMalloc(&b, sizeof(cd) * N2));
   CHECK(hipMalloc(&hhat, sizeof(cd) << LM));
   CHECK(hipMalloc(&r1, sizeof(cd) * N1));
   CHECK(hipMalloc(&tws, sizeof(cd) << LM));
-  CHECK(hipMalloc(&corr, sizeof(double) * 2 * G * stride));
+  CHECK(hipMalloc(&corr, sizeof(double) * 2 * G * (stride + 128)));
   const int h = 44, nch = 2;
-  CHECK(hipMalloc(&T, sizeof(double) * h * nch * 2 * kPfaTC));
+  CHECK(hipMalloc(&T, sizeof(double) * h * 4 * 2 * 22));
   CHECK(hipMalloc(&quad, sizeof(int4) * G));
   std::vector<double> rnd(size_t(mics) * NR * N2 * 2);
   srand(1);
@@ -172,7 +234,7 @@ int main(int argc, char** argv) {
   CHECK(hipMemcpy(hhat, rnd.data(), sizeof(cd) << LM, hipMemcpyHostToDevice));
   CHECK(hipMemcpy(r1, rnd.data(), sizeof(cd) * N1, hipMemcpyHostToDevice));
   CHECK(hipMemcpy(tws, rnd.data(), sizeof(cd) << LM, hipMemcpyHostToDevice));
-  CHECK(hipMemcpy(T, rnd.data(), sizeof(double) * h * nch * 2 * kPfaTC, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(T, rnd.data(), sizeof(double) * h * 4 * 2 * 22, hipMemcpyHostToDevice));
   CHECK(hipMemcpy(Y, rnd.data(), sizeof(cd) * size_t(G < 32 ? G : 32) * n, hipMemcpyHostToDevice));
   std::vector<int4> q(G);
   for (int g = 0; g < G; ++g) {   // consecutive i<j pairs: (i, 2g+1), (i, 2g+2) share the first mic most of the time
@@ -184,6 +246,7 @@ int main(int argc, char** argv) {
   const unsigned grid = unsigned(G) * NR, nblk = (N2 + 63) / 64;
   printf("G = %d transforms (%d pairs)\n", G, 2 * G);
   time_it("rows: product", 20, [&] { k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes)>>>(a); });
+  time_it("rows: product, twiddles from global", 20, [&] { k_pfa_rows<LM, true><<<dim3(grid), dim3(PfaLds<LM>::kLanes)>>>(a); });
   time_it("rows: compute only", 20, [&] { rows_var<LM, 1><<<dim3(grid), dim3(PfaLds<LM>::kLanes)>>>(a); });
   time_it("rows: memory only", 20, [&] { rows_var<LM, 2><<<dim3(grid), dim3(PfaLds<LM>::kLanes)>>>(a); });
   {   // phase clocks of every workgroup of one product launch
@@ -209,11 +272,16 @@ int main(int argc, char** argv) {
   }
   const dim3 cg(unsigned(G) * nblk, 1);
   time_it("cols: product", 20, [&] { k_pfa_cols<kPfaTC><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
-  time_it("cols: variant unroll 1", 20, [&] { cols_var<kPfaTC, 0, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
-  time_it("cols: variant unroll 2", 20, [&] { cols_var<kPfaTC, 0, 2><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
-  time_it("cols: variant unroll 4", 20, [&] { cols_var<kPfaTC, 0, 4><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
-  time_it("cols: no table loads, unroll 1", 20, [&] { cols_var<kPfaTC, 1, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
-  time_it("cols: no table loads, unroll 4", 20, [&] { cols_var<kPfaTC, 1, 4><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
-  time_it("cols: no Y loads, unroll 1", 20, [&] { cols_var<kPfaTC, 2, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: register pipeline, 1 ahead", 20, [&] { cols_pipe<22, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: register pipeline, 2 ahead", 20, [&] { cols_pipe<22, 2><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: register pipeline, 3 ahead", 20, [&] { cols_pipe<22, 3><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: register pipeline, 5 ahead", 20, [&] { cols_pipe<22, 5><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: variant unroll 1", 20, [&] { cols_var<22, 0, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: variant unroll 2", 20, [&] { cols_var<22, 0, 2><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: variant unroll 4", 20, [&] { cols_var<22, 0, 4><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: no table loads, unroll 1", 20, [&] { cols_var<22, 1, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: no table loads, unroll 4", 20, [&] { cols_var<22, 1, 4><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: no Y loads, N2 = 992", 20, [&] { cols_var<22, 2, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, 992, G, nch, T); });
+  time_it("cols: no Y loads, unroll 1", 20, [&] { cols_var<22, 2, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
   return 0;
 }
