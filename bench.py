@@ -55,6 +55,7 @@ def main() -> None:
     ap.add_argument("--cpu-mics", type=int, default=24, help="mics of frame 0 in the CPU baseline / parity sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
+    ap.add_argument("--event-every", type=int, default=4, help="HIP events around every n-th launch group (1 = all)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,7 +128,7 @@ def main() -> None:
         step()
     barrier()
     if not args.no_kernel_events:
-        eng.profile_begin()
+        eng.profile_begin(every=args.event_every)   # HIP events around a sample of the launch groups (they cost idle stream time)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

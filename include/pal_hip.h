@@ -152,9 +152,12 @@ int pal_comm_destroy(pal_handle h);
  * HIP-event timing of the engine's own kernels on its own stream.  Between pal_profile_begin and
  * pal_profile_end every launch is bracketed by events; pal_profile_get returns the summed
  * duration (ms) and launch count of the kernel class `name`, spelled like the kernel's template
- * instance ("k_rows<10,conv>", "k_cols_fwd<8,PairLoader>", "k_peaks", ...). */
+ * instance ("k_rows<10,conv>", "k_pfa_rows<11>", "k_peak_stream", ...).  The events cost a few microseconds of
+ * idle stream each: pal_profile_sampling(h, every) brackets only every `every`-th launch group of the pair
+ * pipeline (averages are unchanged, the run is barely perturbed); the default is 1 = every group. */
 int pal_profile_begin(pal_handle h);
 int pal_profile_end(pal_handle h);
+int pal_profile_sampling(pal_handle h, int every);
 int pal_profile_get(pal_handle h, const char* name, double* total_ms, int64_t* launches);
 /* enumerate the kernel classes seen so far: index 0.. until PAL_ERR_INVALID */
 int pal_profile_entry(pal_handle h, int index, char* name, int cap, double* total_ms, int64_t* launches);

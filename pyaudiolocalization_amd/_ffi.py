@@ -78,6 +78,7 @@ SIGNATURES = {
     "pal_comm_destroy": (C.c_int, [_H]),
     "pal_profile_begin": (C.c_int, [_H]),
     "pal_profile_end": (C.c_int, [_H]),
+    "pal_profile_sampling": (C.c_int, [_H, C.c_int]),
     "pal_profile_get": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pal_profile_entry": (C.c_int, [_H, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pal_plan_info": (C.c_int, [_H, C.c_int, _PI, _PI, _PI, _PI]),

@@ -306,12 +306,19 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     const int rows = int(npairs - p0 < 2 * G ? npairs - p0 : 2 * G);
     const int slot = two ? int(group & 1) : 0;
     hipStream_t on = slot ? stream2 : stream;
+    prof_gate = prof_every <= 1 || (prof_tick++ % prof_every) == 0;
     cd* Wg = W + size_t(slot) * wpoints;
     // odd tail with a caller buffer: the imaginary half of the last transform has no destination row there
     const bool via_scratch = !corr_out || rows < 2 * G;
     double* crow = via_scratch ? cbuf + size_t(slot) * buf_doubles : corr_out + size_t(p0) * stride;
     if (pfa) {
-      PAL_TRY(pfa_pair_group(pl, permuted, quads + t0, G, Wg, crow, stride, on));
+      // sub-groups: the Y of a sub-group (1.4 MB per transform) is still in the Infinity Cache when the column
+      // pass reads it back, while the peak kernels keep whole launch groups (their fixed costs want many rows)
+      const int sub = pfa_sub > 0 && pfa_sub < G ? pfa_sub : G;
+      for (int g0 = 0; g0 < G; g0 += sub) {
+        const int Gs = G - g0 < sub ? G - g0 : sub;
+        PAL_TRY(pfa_pair_group(pl, permuted, quads + t0 + g0, Gs, Wg, crow + size_t(2 * g0) * stride, stride, on));
+      }
     } else {
       PairLoader ld{spectra, quads + t0, n, pl.H, pl.w};
       CorrStorer st{crow, stride, n, pl.w};
@@ -325,6 +332,7 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     if (table)
       PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr, on));
   }
+  prof_gate = true;
   if (two) {   // whatever follows on `stream` (downloads, the RCCL gather) sees the finished table
     PAL_HIP(hipEventRecord(ev_peaks[0], stream2));
     PAL_HIP(hipStreamWaitEvent(stream, ev_peaks[0], 0));

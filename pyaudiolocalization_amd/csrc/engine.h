@@ -70,6 +70,7 @@ struct Engine {
   bool overlap = true;             // alternate launch groups between the two streams (PAL_OVERLAP=0 turns it off)
   bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
   bool allow_pfa = true;           // PAL_PFA=0 keeps the PHAT inverse on the four-step chirp convolution
+  int pfa_sub = 0;                 // transforms per row/column pass of the prime-factor route (PAL_PFA_SUB; 0 = whole group)
   std::string err;
   int chunk = 128;                              // transforms per launch group (256 PHAT rows per peak-kernel launch: one per CU)
   std::map<std::tuple<int, int, int>, Plan> plans;   // (n, lin, nout) -> plan
@@ -80,6 +81,9 @@ struct Engine {
   size_t ws_bytes[16] = {};
   // profiling
   bool profiling = false;
+  int prof_every = 1;              // pair pipeline: events around every prof_every-th launch group only
+  long long prof_tick = 0;
+  bool prof_gate = true;           // false while an unsampled launch group is being enqueued
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   struct Pending { int slot; hipEvent_t a, b; };
@@ -126,7 +130,7 @@ struct ProfScope {
   hipEvent_t a = nullptr;
   hipStream_t on;
   ProfScope(Engine* eng, const char* name, hipStream_t s = nullptr) : e(eng), slot(-1), on(s ? s : eng->stream) {
-    if (e->profiling) {
+    if (e->profiling && e->prof_gate) {
       slot = e->prof_slot(name);
       e->prof_begin(slot, &a, on);
     }

@@ -227,6 +227,8 @@ int pal_create(int device, pal_handle* out) {
   if (env) e->allow_r3 = atoi(env) != 0;
   env = getenv("PAL_PFA");
   if (env) e->allow_pfa = atoi(env) != 0;
+  env = getenv("PAL_PFA_SUB");
+  if (env) e->pfa_sub = atoi(env);
   *out = reinterpret_cast<pal_handle>(e);
   return PAL_OK;
 }
@@ -432,6 +434,14 @@ int pal_profile_begin(pal_handle h) {
   return PAL_OK;
 }
 
+int pal_profile_sampling(pal_handle h, int every) {
+  ENGINE(h);
+  if (every < 1) return e->fail(PAL_ERR_INVALID, "sampling period must be >= 1");
+  e->prof_every = every;
+  e->prof_tick = 0;
+  return PAL_OK;
+}
+
 int pal_profile_end(pal_handle h) {
   ENGINE(h);
   PAL_TRY(e->check(hipStreamSynchronize(e->stream), "stream sync"));
@@ -453,8 +463,6 @@ int pal_profile_get(pal_handle h, const char* name, double* total_ms, int64_t* l
   if (launches) *launches = 0;
   return PAL_OK;
 }
-
-
 
 int pal_profile_entry(pal_handle h, int index, char* name, int cap, double* total_ms, int64_t* launches) {
   ENGINE(h);

@@ -272,7 +272,9 @@ class Engine:
         self._check(self._lib.pal_comm_destroy(self._h))
 
     # ---- measurement ---------------------------------------------------------------------
-    def profile_begin(self) -> None:
+    def profile_begin(self, every: int = 1) -> None:
+        """Bracket the engine's launches with HIP events (every `every`-th launch group of the pair pipeline)."""
+        self._check(self._lib.pal_profile_sampling(self._h, int(every)))
         self._check(self._lib.pal_profile_begin(self._h))
 
     def profile_end(self) -> None:

@@ -22,17 +22,30 @@ static void make_stage_tw(int ln, std::vector<cd>& tw) {
   }
 }
 
-// every stage through the LDS-tile accessor, reads of a stage before its writes (what the barriers enforce)
-template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB = (kPoints >> LOG2N)>
+// the compact table of the prime-factor row pass: the last stage keeps the rows r = 1, 2, 4 (, 8) only
+static void make_stage_tw_compact(int ln, std::vector<cd>& tw) {
+  make_stage_tw(ln, tw);
+  const int lp = stage_tw_last(ln), R = stage_radix(ln, lp), P = 1 << lp, off = stage_tw_offset(ln, lp);
+  for (int i = off; i < (1 << ln); ++i) tw[i] = mk(1e300, 1e300);       // poison what the compact layout must not read
+  for (int b = 0; (1 << b) < R; ++b)
+    for (int k = 0; k < P; ++k) {
+      const double a = -2.0 * M_PI * double(k * (1 << b)) / double(P * R);
+      tw[off + b * P + k] = mk(std::cos(a), std::sin(a));
+    }
+}
+
+// every stage through the LDS-tile accessor, reads of a stage before its writes (what the barriers enforce);
+// STOP: first stage NOT to run (LOG2N = all of them)
+template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB = (kPoints >> LOG2N), bool COMPACT = false, int STOP = LOG2N>
 static void emu_from(std::vector<cd>& data, const std::vector<cd>& tw) {
-  if constexpr (LOG2P < LOG2N) {
+  if constexpr (LOG2P < STOP) {
     constexpr int R = stage_radix(LOG2N, LOG2P);
     constexpr int ITEMS = (NSUB << LOG2N) / R;
     const LdsTile<LOG2N, COLS, NSUB> tile{data.data()};
     std::vector<cd> regs(size_t(ITEMS) * R);
-    for (int w = 0; w < ITEMS; ++w) stage_load<LOG2N, COLS, INV, LOG2P, NSUB>(tile, tw.data(), w, &regs[size_t(w) * R]);
+    for (int w = 0; w < ITEMS; ++w) stage_load<LOG2N, COLS, INV, LOG2P, NSUB, COMPACT>(tile, tw.data(), w, &regs[size_t(w) * R]);
     for (int w = 0; w < ITEMS; ++w) stage_store<LOG2N, COLS, LOG2P, NSUB>(tile, w, &regs[size_t(w) * R]);
-    emu_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P), NSUB>(data, tw);
+    emu_from<LOG2N, COLS, INV, LOG2P + stage_log2r(LOG2N, LOG2P), NSUB, COMPACT, STOP>(data, tw);
   }
 }
 
@@ -115,9 +128,63 @@ template <int LOG2N> static int run() {
   return bad;
 }
 
+// ---- the in-LDS circular convolution of the prime-factor row pass (pfa_kernels.h, k_pfa_rows steps 2-4), two
+// tiles of M points: forward stages, then the fused seam (last forward stage, pointwise product, first inverse
+// stage on the same sixteen registers, lane mapping as in the kernel), then the remaining inverse stages
+template <int LM> static int run_conv() {
+  constexpr int M = 1 << LM, NB = M / 16, LANES = 2 * M / 16;
+  constexpr bool CT = LM >= 11;
+  constexpr int LPL = stage_tw_last(LM), RL = stage_radix(LM, LPL), P = 1 << LPL, SPLIT = 16 / RL;
+  std::vector<cd> tw;
+  if (CT) make_stage_tw_compact(LM, tw); else make_stage_tw(LM, tw);
+  std::vector<cd> data(2 * M), x(2 * M), hh(M);
+  const LdsTile<LM, false, 2> tile{data.data()};
+  for (int t = 0; t < 2; ++t)
+    for (int e = 0; e < M; ++e) { x[t * M + e] = mk(drand48() - 0.5, drand48() - 0.5); tile(t, e, x[t * M + e]); }
+  for (int e = 0; e < M; ++e) hh[e] = mk(drand48() - 0.5, drand48() - 0.5);
+  emu_from<LM, false, false, 0, 2, CT, LPL>(data, tw);                       // forward, all stages but the last
+  std::vector<cd> regs(size_t(LANES) * 16);
+  for (int tid = 0; tid < LANES; ++tid) {                                    // seam: every read ...
+    const int t = tid / NB, i = tid % NB;
+    cd* u = &regs[size_t(tid) * 16];
+    for (int q = 0; q < SPLIT; ++q) {
+      cd v[RL];
+      const int k = i + NB * q;
+      stage_load<LM, false, false, LPL, 2, CT>(tile, tw.data(), t * P + k, v);
+      for (int r = 0; r < RL; ++r) u[q + SPLIT * r] = cmul(v[r], hh[k + P * r]);
+    }
+    dft16<true>(u);
+  }
+  for (int tid = 0; tid < LANES; ++tid) stage_store<LM, false, 0, 2>(tile, tid, &regs[size_t(tid) * 16]);   // ... before any write
+  emu_from<LM, false, true, 4, 2, CT>(data, tw);                             // inverse, the stages after the first
+  // reference: y = IDFT(DFT(x) . hh), unnormalised like the kernel
+  double worst = 0;
+  for (int t = 0; t < 2; ++t) {
+    std::vector<cd> X(M);
+    for (int k = 0; k < M; ++k) {
+      long double sx = 0, sy = 0;
+      for (int e = 0; e < M; ++e) {
+        const long double a = -2.0L * M_PIl * (long double)((long long)k * e % M) / M;
+        sx += x[t * M + e].x * cosl(a) - x[t * M + e].y * sinl(a);
+        sy += x[t * M + e].x * sinl(a) + x[t * M + e].y * cosl(a);
+      }
+      X[k] = cmul(mk(double(sx), double(sy)), hh[k]);
+    }
+    for (int o = 0; o < M; o += 37) worst = std::fmax(worst, naive_err(X, 0, M, o, true, tile(t, o)));
+  }
+  worst /= double(M);
+  const int bad = !(worst < 1e-13);
+  std::printf("M=%5d in-LDS convolution (compact twiddles %d, seam %d x radix-%d) err %.2e %s\n", M, int(CT), SPLIT, RL, worst,
+              bad ? "FAIL" : "ok");
+  return bad;
+}
+
 int main() {
   srand48(12345);
   int bad = 0;
+  bad += run_conv<10>();
+  bad += run_conv<11>();
+  bad += run_conv<12>();
   bad += run<4>();
   bad += run<5>();
   bad += run<6>();

@@ -35,6 +35,65 @@ def test_phat_correlation_matches_numpy(engine, n1, n2):
     assert np.max(np.abs(got - want)) <= 5e-14, float(np.max(np.abs(got - want)))
 
 
+# frame lengths whose n = 2L-1 exercises every shape of the prime-factor route (pfa.hip): one row tile
+# (99 = 1 x 99, 999 = 1 x 999), dense column DFTs with N1 = 9 / 7 / 3 / 11 / 89, tiles of 1024 / 2048 / 4096 points,
+# and lengths that have no usable split (1999 prime) and stay on the four-step chirp convolution
+PFA_LENGTHS = [(50, 1, 99, 1024), (500, 1, 999, 2048), (1000, 0, 0, 0), (2048, 9, 455, 1024), (2999, 3, 1999, 4096),
+               (3000, 7, 857, 2048), (5000, 11, 909, 2048), (44100, 89, 991, 2048)]
+
+
+@pytest.mark.parametrize("length,n1,n2,tile", PFA_LENGTHS)
+def test_prime_factor_route_matches_four_step_and_numpy(engine, length, n1, n2, tile, monkeypatch):
+    """The two inverse-transform routes are independent code (CRT maps + in-LDS chirp convolutions + dense column
+    DFTs against the four-step workspace passes): both must reproduce numpy's exact-length ifft to rounding."""
+    from pyaudiolocalization_amd import Engine
+    info = engine.plan_info(length)
+    assert (info["n1"], info["n2"], info["tile_len"]) == (n1, n2, tile), info
+    if n1:
+        assert n1 * n2 == info["n"]
+    rng = np.random.default_rng(length)
+    a, b = rng.standard_normal(length), rng.standard_normal(length)
+    want = O.phat_correlation(a, b)
+    got = engine.phat_correlation(a, b)
+    monkeypatch.setenv("PAL_PFA", "0")
+    plain = Engine(engine.device)
+    try:
+        assert plain.plan_info(length)["n1"] == 0
+        ref = plain.phat_correlation(a, b)
+    finally:
+        plain.close()
+    scale = np.max(np.abs(want))
+    assert np.max(np.abs(got - want)) <= 1e-12 * scale          # fp64 rounding of a length-n transform: ~1e-14
+    assert np.max(np.abs(ref - want)) <= 1e-12 * scale
+    assert int(np.argmax(got)) == int(np.argmax(want)) == int(np.argmax(ref))
+
+
+def test_prime_factor_route_odd_pair_counts_and_tables(engine, monkeypatch):
+    """5 mics = 10 pairs = 5 packed transforms, 3 mics = 3 pairs (one half-empty transform): tables and
+    sequences of the prime-factor route equal the four-step route's."""
+    from pyaudiolocalization_amd import Engine
+    rng = np.random.default_rng(77)
+    monkeypatch.setenv("PAL_PFA", "0")
+    plain = Engine(engine.device)
+    try:
+        for mics, length, fs, med in ((5, 3000, 16000.0, 0.004), (3, 2048, 8000.0, None), (6, 500, 8000.0, None)):
+            frames = rng.standard_normal((2, mics, length))
+            frames[:, 1:] += 0.6 * frames[:, :1]
+            t1, c1 = engine.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, want_corr=True)
+            t0, c0 = plain.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, want_corr=True)
+            assert np.max(np.abs(c1 - c0)) <= 1e-13
+            for name in ("k_sel", "branch", "k_argmax", "n_sel"):
+                assert np.array_equal(t1[name], t0[name]), name
+            for b in range(2):
+                want = O.all_pairs(frames[b], fs, max_expected_delay=med)
+                for name in ("k_sel", "branch", "k_argmax"):
+                    assert np.array_equal(t1[b][name], want[name]), name        # bit-exact integer outputs
+                assert np.allclose(t1[b]["cmax"], want["cmax"], rtol=1e-11, atol=0)
+                assert np.allclose(t1[b]["snr"], want["snr"], rtol=1e-9, atol=0)
+    finally:
+        plain.close()
+
+
 def test_phat_of_identical_and_silent_signals(engine):
     x = np.random.default_rng(1).standard_normal(500)
     assert np.argmax(engine.phat_correlation(x, x)) == 0

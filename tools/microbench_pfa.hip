@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -136,6 +137,36 @@ __global__ __launch_bounds__(256) void cols_pipe(const cd* __restrict__ Y, doubl
       out[size_t(N2) * t] = base + accC[tt] + s;
       out[size_t(N2) * (N1 - t)] = base + accC[tt] - s;
     }
+  }
+}
+
+// ---- column pass traffic only: every load of a wave in flight at once, the same stores, no arithmetic
+template <int MODE>   // 0: product layout Y[k1][N2];  1: blocked layout Y[cb][k1][64] (contiguous per workgroup)
+__global__ __launch_bounds__(256) void cols_copy(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
+                                                 int N1, int N2, int G) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+  const int role = wave & 1, ch = wave >> 1;
+  const int g = blockIdx.x % G, cb = blockIdx.x / G;
+  const int m2 = cb * 64 + lane;
+  const bool live = m2 < N2;
+  const cd* Yg = MODE == 0 ? Y + size_t(g) * N1 * N2 + (live ? m2 : N2 - 1) : Y + size_t(g) * N1 * N2 + size_t(cb) * N1 * 64 + lane;
+  const size_t rs = MODE == 0 ? size_t(N2) : 64;
+  double acc[2] = {0, 0};
+  // each wave reads every row once (like the product: four waves share the rows through L1)
+  for (int j0 = 0; j0 < 88; j0 += 22) {
+    cd v[22];
+#pragma unroll
+    for (int u = 0; u < 22; ++u) v[u] = Yg[size_t(j0 + u) * rs];
+#pragma unroll
+    for (int u = 0; u < 22; ++u) { acc[0] += v[u].x; acc[1] += v[u].y; }
+  }
+  if (!live) return;
+  double* out = corr + size_t(2 * g + role) * stride + m2;
+  for (int tt = 0; tt < 22; ++tt) {
+    const int t = ch * 22 + tt + 1;
+    out[size_t(N2) * t] = acc[0];
+    out[size_t(N2) * (N1 - t)] = acc[1];
   }
 }
 
@@ -272,6 +303,8 @@ int main(int argc, char** argv) {
   }
   const dim3 cg(unsigned(G) * nblk, 1);
   time_it("cols: product", 20, [&] { k_pfa_cols<kPfaTC><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: traffic only, product layout", 20, [&] { cols_copy<0><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G); });
+  time_it("cols: traffic only, blocked Y layout", 20, [&] { cols_copy<1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G); });
   time_it("cols: register pipeline, 1 ahead", 20, [&] { cols_pipe<22, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
   time_it("cols: register pipeline, 2 ahead", 20, [&] { cols_pipe<22, 2><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
   time_it("cols: register pipeline, 3 ahead", 20, [&] { cols_pipe<22, 3><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
@@ -283,5 +316,49 @@ int main(int argc, char** argv) {
   time_it("cols: no table loads, unroll 4", 20, [&] { cols_var<22, 1, 4><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
   time_it("cols: no Y loads, N2 = 992", 20, [&] { cols_var<22, 2, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, 992, G, nch, T); });
   time_it("cols: no Y loads, unroll 1", 20, [&] { cols_var<22, 2, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  {   // do the row pass (VALU / LDS) and the column pass (memory) overlap when launched on two streams?
+    hipStream_t sa, sb;
+    CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    cd* Y2;
+    CHECK(hipMalloc(&Y2, sizeof(cd) * size_t(G) * (n + 128)));
+    PfaRowsArgs a2 = a;
+    a2.Y = Y2;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    double* corr2;
+    CHECK(hipMalloc(&corr2, sizeof(double) * 2 * G * (stride + 128)));
+    for (int mode = 3; mode < 7; ++mode) {
+      CHECK(hipDeviceSynchronize());
+      auto t0 = std::chrono::steady_clock::now();
+      const int reps = 20;
+      for (int i = 0; i < reps; ++i) {
+        if (mode == 3 || mode == 4) {
+          k_pfa_cols<kPfaTC><<<cg, dim3(256), 0, sa>>>(Y, corr, stride, N1, N2, G, nch, T);
+          k_pfa_cols<kPfaTC><<<cg, dim3(256), 0, mode == 4 ? sb : sa>>>(Y2, corr2, stride, N1, N2, G, nch, T);
+        } else {
+          k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, sa>>>(a);
+          k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, mode == 6 ? sb : sa>>>(a2);
+        }
+      }
+      CHECK(hipDeviceSynchronize());
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+      const char* nm[4] = {"cols, cols on one stream", "cols || cols on two streams", "rows, rows on one stream", "rows || rows on two streams"};
+      printf("  %-44s %8.1f us per iteration (wall)\n", nm[mode - 3], us);
+    }
+    for (int mode = 0; mode < 3; ++mode) {
+      CHECK(hipDeviceSynchronize());
+      auto t0 = std::chrono::steady_clock::now();
+      const int reps = 20;
+      for (int i = 0; i < reps; ++i) {
+        if (mode != 1) k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, sa>>>(a2);
+        if (mode != 0) k_pfa_cols<kPfaTC><<<cg, dim3(256), 0, mode == 2 ? sb : sa>>>(Y, corr, stride, N1, N2, G, nch, T);
+      }
+      CHECK(hipDeviceSynchronize());
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+      printf("  %-44s %8.1f us per iteration (wall)\n", mode == 0 ? "rows alone" : mode == 1 ? "cols alone" : "rows || cols on two streams", us);
+    }
+  }
   return 0;
 }
