@@ -41,6 +41,7 @@ struct Pfa {
   cd* hhat = nullptr;      // FFT_M of the conjugate chirp kernel, scaled by 1 / (M n)
   cd* r1 = nullptr;        // exp(-2 pi i q / N1), q < N1
   double* T = nullptr;     // cos / sin (2 pi j t / N1) in the column pass's chunked order
+  int2* rowtab = nullptr;  // per row of Y: (u1 row mod N1, its step between outputs of a last-stage butterfly)
   int rows() const { return (n1 + 1) / 2; }   // spectrum rows k1 <= (N1-1)/2 kept by the permuted layout
   bool on() const { return n1 > 0; }
 };

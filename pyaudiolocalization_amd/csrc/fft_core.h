@@ -162,12 +162,29 @@ template <int LOG2N, bool COLS, int NSUB = (kPoints >> LOG2N)> PAL_HD int lds_ad
 }
 
 // element accessors of the in-LDS tile (the default source / sink of a stage)
+//
+// A stage touches elements e = e0 + c with a per-lane part e0 and a compile-time part c whose bits do not
+// overlap (e0 = i < N/R, c = r N/R on the load side; e0 = j0, c = r P on the store side).  The XOR swizzle of the
+// rows layout then splits as well, swz(e0 | c) = swz(e0) ^ swz(c), so the address is `base(t, e0)` once per work
+// item plus, per element, a constant offset and at most one XOR with a constant below 8 - instead of a fresh
+// swizzle per element (a fifth of the row kernels' vector instructions were address arithmetic).
 template <int LOG2N, bool COLS, int NSUB = (kPoints >> LOG2N)> struct LdsTile {
   static constexpr bool kLds = true;
+  static constexpr bool kDirect = true;     // offers base() / at(): stage_load / stage_store use the split addressing
   cd* data;
   PAL_HD cd operator()(int t, int e) const { return data[lds_addr<LOG2N, COLS, NSUB>(t, e)]; }
   PAL_HD void operator()(int t, int e, cd v) const { data[lds_addr<LOG2N, COLS, NSUB>(t, e)] = v; }
+  PAL_HD int base(int t, int e0) const { return lds_addr<LOG2N, COLS, NSUB>(t, e0); }
+  static PAL_HD constexpr int split(int b, int c) {   // address of element e0 | c given b = base(t, e0)
+    // rows: (e0 | c) ^ swz(e0) ^ swz(c); bits >= 3 of c meet zeros of b (add = xor: an immediate offset), bits 0-2 are xor-ed
+    return COLS ? b + c * NSUB : (b ^ ((c ^ (c >> 3) ^ (c >> 6)) & 7)) + (c & ~7);
+  }
+  PAL_HD cd at(int b, int c) const { return data[split(b, c)]; }
+  PAL_HD void at(int b, int c, cd v) const { data[split(b, c)] = v; }
 };
+
+template <class T, class = void> struct has_direct { static constexpr bool value = false; };
+template <class T> struct has_direct<T, decltype(void(T::kDirect))> { static constexpr bool value = true; };
 
 // work item w in [0, POINTS/R) -> (butterfly i, sub-transform t)
 template <int LOG2N, bool COLS, int R, int NSUB = (kPoints >> LOG2N)> PAL_HD void item_of(int w, int& i, int& t) {
@@ -181,8 +198,14 @@ PAL_HD void stage_load(const In& in, const cd* tw, int w, cd* v) {
   constexpr int R = stage_radix(LOG2N, LOG2P), N = 1 << LOG2N, P = 1 << LOG2P, NB = N / R;
   int i, t;
   item_of<LOG2N, COLS, R, NSUB>(w, i, t);
+  if constexpr (has_direct<In>::value) {
+    const int b = in.base(t, i);
 #pragma unroll
-  for (int r = 0; r < R; ++r) v[r] = in(t, i + r * NB);
+    for (int r = 0; r < R; ++r) v[r] = in.at(b, r * NB);
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = in(t, i + r * NB);
+  }
   if (P > 1) {
     const int k = i & (P - 1);
     const cd* tws = tw + stage_tw_offset(LOG2N, LOG2P);
@@ -216,8 +239,14 @@ PAL_HD void stage_store(const Out& out, int w, const cd* v) {
   item_of<LOG2N, COLS, R, NSUB>(w, i, t);
   const int k = i & (P - 1);
   const int j0 = (i - k) * R + k;
+  if constexpr (has_direct<Out>::value) {
+    const int b = out.base(t, j0);
 #pragma unroll
-  for (int r = 0; r < R; ++r) out(t, j0 + r * P, v[r]);
+    for (int r = 0; r < R; ++r) out.at(b, r * P, v[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) out(t, j0 + r * P, v[r]);
+  }
 }
 
 // ---------------------------------------------------------------- radix-3 outer stage (column mode)

@@ -47,6 +47,7 @@ void Engine::free_pfa(Pfa& f) {
   if (f.hhat) (void)hipFree(f.hhat);
   if (f.r1) (void)hipFree(f.r1);
   if (f.T) (void)hipFree(f.T);
+  if (f.rowtab) (void)hipFree(f.rowtab);
   f = Pfa();
 }
 
@@ -106,6 +107,19 @@ int Engine::build_pfa(Plan& pl) {
       row[tt] = double(cosl(ang));
       row[kPfaTC + tt] = double(sinl(ang));
     }
+  // twiddle bookkeeping of the row pass's last stage: per row of Y the index multiplier and its step (pfa_kernels.h)
+  {
+    const int ll = stage_tw_last(blm);
+    const long long P = 1ll << ll;
+    std::vector<int2> rt;
+    rt.resize(size_t(bn1));
+    for (int row = 0; row < bn1; ++row) {
+      const long long uk = (long long)f.u1 * row % bn1;
+      rt[size_t(row)] = make_int2(int(uk), int(uk * P % bn1));
+    }
+    PAL_HIP(hipMalloc(&f.rowtab, rt.size() * sizeof(int2)));
+    PAL_HIP(hipMemcpy(f.rowtab, rt.data(), rt.size() * sizeof(int2), hipMemcpyHostToDevice));
+  }
   PAL_HIP(hipMalloc(&f.T, tab.size() * sizeof(double)));
   PAL_HIP(hipMemcpyAsync(f.T, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, stream));
   PAL_HIP(hipStreamSynchronize(stream));       // `tab` is host memory
@@ -129,7 +143,7 @@ int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads
     char name[48];
     snprintf(name, sizeof name, "k_pfa_rows<%d>", f.lm);
     ProfScope ps(this, name, on);
-    PfaRowsArgs a{permuted, quads, Y, f.b, f.hhat, f.r1, tws, f.n1, f.n2, f.rows(), G, f.u1, 1.0f / float(f.n1), nullptr};
+    PfaRowsArgs a{permuted, quads, Y, f.b, f.hhat, f.r1, tws, f.rowtab, f.n1, f.n2, f.rows(), G, f.u1, 1.0f / float(f.n1), nullptr};
     const unsigned grid = unsigned(G) * unsigned(f.rows());
     PAL_SWITCH_LM(f.lm, k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, on>>>(a));
     PAL_HIP(hipGetLastError());

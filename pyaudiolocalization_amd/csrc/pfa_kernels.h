@@ -30,28 +30,6 @@ template <int LM> struct PfaHhatToLds {   // last stage of the forward FFT: time
   __device__ void operator()(int t, int e, cd v) const { data[lds_addr<LM, false, 2>(t, e)] = cmul(v, hh[e]); }
 };
 
-template <int LM> struct PfaOut {         // last stage of the inverse FFT: chirp, column twiddle, store Y[row][m2]
-  static constexpr bool kLds = false;
-  cd* Yg;                                 // Y of this transform: [N1][N2]
-  const cd *b, *r1;
-  int N1, N2, k1, uk0, uk1;               // uk_t = u1 * row_t mod N1
-  float inv;
-  __device__ void operator()(int t, int e, cd v) const {
-    constexpr int HALF = 1 << (LM - 1);
-    if (e >= HALF) return;
-    const int ee = e < N2 ? e : N2 - 1;
-    const int m2 = t == 0 ? ee : (ee ? N2 - ee : 0);
-    const int row = t == 0 ? k1 : N1 - k1;
-    const unsigned x = unsigned(t == 0 ? uk0 : uk1) * unsigned(m2);     // < 2^24: exact in float
-    const unsigned q = unsigned(float(x) * inv);
-    int r = int(x) - int(q) * N1;
-    if (r < 0) r += N1;
-    if (r >= N1) r -= N1;
-    const cd z = cmulc(cmul(v, b[ee]), r1[r]);                           // r1 holds exp(-2 pi i q / N1)
-    if (e < N2 && !(t == 1 && k1 == 0)) Yg[size_t(row) * N2 + m2] = z;
-  }
-};
-
 template <int LM> struct PfaChirpIn {     // chirp kernel of the convolution: h[d mod M] = conj(b[|d|]), |d| < N2
   static constexpr bool kLds = false;
   const cd* b;
@@ -93,17 +71,24 @@ struct PfaRowsArgs {
   const int4* quad;    // mic rows (a, b) of pair p and (c, d) of pair q; c < 0: no second pair
   cd* Y;               // [G][N1][N2]
   const cd *b, *hhat, *r1, *tws;
+  const int2* rowtab;  // per row of Y: (u1 row mod N1, u1 row P mod N1) with P = points per last-stage butterfly group
   int N1, N2, NR, G, u1;
   float inv;
   unsigned long long* stamps;   // diagnostics only (tools/microbench_pfa): 100 MHz clock reads of lane 0 per phase
 };
 
-// partner lane's value across the two halves of a wavefront (lane ^ 32)
-__device__ __forceinline__ double swap_halves(double v, bool upper) {
-  const unsigned lo = unsigned(__double2loint(v)), hi = unsigned(__double2hiint(v));
-  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double(int(upper ? b[0] : b[1]), int(upper ? a[0] : a[1]));
+// v_permlane32_swap(x, y): x' = {x[0:31], y[0:31]}, y' = {x[32:63], y[32:63]} (lane ranges of the two results).
+// first_of(a, b):  lanes 0-31 keep a, lanes 32-63 receive b of their partner lane (lane - 32)
+// second_of(a, b): lanes 0-31 receive a of their partner lane (lane + 32), lanes 32-63 keep b
+__device__ __forceinline__ double first_of(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(unsigned(__double2loint(a)), unsigned(__double2loint(b)), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(unsigned(__double2hiint(a)), unsigned(__double2hiint(b)), false, false);
+  return __hiloint2double(int(hi[0]), int(lo[0]));
+}
+__device__ __forceinline__ double second_of(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(unsigned(__double2loint(a)), unsigned(__double2loint(b)), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(unsigned(__double2hiint(a)), unsigned(__double2hiint(b)), false, false);
+  return __hiloint2double(int(hi[1]), int(lo[1]));
 }
 
 // grid = G * NR workgroups, transform fastest so that neighbours share the tables.
@@ -172,24 +157,22 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
       const int idx = tid + q * L::kLanes;
       if (idx < L::kTw) tw_lds[idx] = twr[q];
     }
-    cd mine[4], recv[4];
+    // Lower lanes (tile 0) whiten inputs r = 0..3 of butterfly i, upper lanes (tile 1) r = 4..7.  Each lane forms its
+    // own tile's value `own` and the other tile's value `oth` of the same bin: with sg = +1 / -1 for tile 0 / 1
+    //   tile 0: R^p + i R^q,  tile 1: conj(R^p) + i conj(R^q)   =>   own = (r1.x - sg r2.y, sg r1.y + r2.x), oth = own(-sg)
+    // and two half-wave swaps per register put r = 0..3 / 4..7 of BOTH tiles where their butterflies expect them.
+    const double sg = upper ? -1.0 : 1.0;
+    cd v[16];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = i + NB * (u + (upper ? 4 : 0));
       const cd r1 = whiten(va[u], vb[u]);
       const cd r2 = cscale(whiten(vc[u], vd[u]), keep2);
-      // tile 0: R^p + i R^q at (k1, e);  tile 1: conj(R^p) + i conj(R^q) = the reversed row N1 - k1
-      cd x = cmul(mk(r1.x - r2.y, r1.y + r2.x), ch[u]), z = cmul(mk(r1.x + r2.y, r2.x - r1.y), ch[u]);
-      if (e >= a.N2) x = z = mk(0, 0);
-      mine[u] = upper ? z : x;
-      const cd send = upper ? x : z;
-      recv[u] = mk(swap_halves(send.x, upper), swap_halves(send.y, upper));
-    }
-    cd v[16];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      v[u] = upper ? recv[u] : mine[u];
-      v[4 + u] = upper ? mine[u] : recv[u];
+      const cd c0 = e < a.N2 ? ch[u] : mk(0, 0);             // zero padding beyond N2
+      const cd own = cmul(mk(__builtin_fma(-sg, r2.y, r1.x), __builtin_fma(sg, r1.y, r2.x)), c0);
+      const cd oth = cmul(mk(__builtin_fma(sg, r2.y, r1.x), __builtin_fma(-sg, r1.y, r2.x)), c0);
+      v[u] = mk(first_of(own.x, oth.x), first_of(own.y, oth.y));          // r = u:     tile 0 own, tile 1 from its partner
+      v[4 + u] = mk(second_of(oth.x, own.x), second_of(oth.y, own.y));    // r = 4 + u: tile 0 from its partner, tile 1 own
       v[8 + u] = v[12 + u] = mk(0, 0);
     }
     dft16<false>(v);
@@ -223,10 +206,46 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
   }
   stamp();
 
-  // ---- 4. remaining inverse stages
-  const int kr = k1 ? a.N1 - k1 : 0;
-  const PfaOut<LM> out{a.Y + size_t(g) * a.N1 * a.N2, a.b, a.r1, a.N1, a.N2, k1, (a.u1 * k1) % a.N1, (a.u1 * kr) % a.N1, a.inv};
-  wg_fft_from<LM, false, true, 4, 2, CT>(data, tw, tid, tile, out);
+  // ---- 4. remaining inverse stages; the last one is hand-mapped: only outputs e < M/2 can be below N2, each is
+  //         scaled by the chirp b[e] and by the column twiddle exp(2 pi i u1 row m2 / N1) and stored at Y[row][m2]
+  //         (tile 0: row k1, m2 = e; tile 1: row N1 - k1 of the reversed transform, m2 = -e mod N2).  The twiddle
+  //         index u1 row m2 mod N1 advances by a wave-uniform step from one output of a butterfly to the next.
+  wg_fft_middle<LM, false, true, 4, 2, CT>(data, tw, tid);
+  {
+    constexpr int LPL = stage_tw_last(LM), RL = stage_radix(LM, LPL), P = 1 << LPL, PER = 16 / RL;
+    cd* const Yg = a.Y + size_t(g) * a.N1 * a.N2;
+    const int N1 = a.N1, N2 = a.N2;
+    const int kr = k1 ? N1 - k1 : 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int w = tid + L::kLanes * q;
+      const int t = __builtin_amdgcn_readfirstlane(w / P), k = w % P;   // tile (wave-uniform), butterfly
+      cd v[RL];
+      stage_load<LM, false, true, LPL, 2, CT>(tile, tw, w, v);
+      if (t == 1 && k1 == 0) continue;                                  // row 0 pairs with itself: tile 1 is a duplicate
+      const int row = t ? kr : k1;
+      const int2 rt = a.rowtab[row];                                    // scalar: u1 row mod N1 and the index step between outputs
+      const unsigned uk = unsigned(rt.x), step = unsigned(rt.y), n1 = unsigned(N1);
+      const int mb = t ? N2 - k : k;                                    // m2 of output r is mb -/+ P r (tile 1: except e = 0)
+      const unsigned x = __umul24(uk, unsigned(mb));                    // < 2^24: exact in float
+      unsigned idx = x - __umul24(unsigned(float(x) * a.inv), n1);      // x mod N1, off by at most one N1 either way
+      idx = min(idx, idx + n1);                                         // (unsigned wrap-around picks the in-range value)
+      idx = min(idx, idx - n1);
+      cd* const Yrow = Yg + size_t(row) * N2;
+#pragma unroll
+      for (int r = 0; r < RL / 2; ++r) {
+        const int e = k + P * r;
+        const int ee = e < N2 ? e : N2 - 1;
+        int m2 = t ? mb - P * r : e;
+        unsigned ti = idx;
+        if (t && e == 0) { m2 = 0; ti = 0; }
+        const cd z = cmulc(cmul(v[r], a.b[ee]), a.r1[ti]);              // r1 holds exp(-2 pi i q / N1)
+        if (e < N2) Yrow[m2] = z;
+        if (t) { idx -= step; idx = min(idx, idx + n1); }
+        else { idx += step; idx = min(idx, idx - n1); }
+      }
+    }
+  }
   stamp();
 }
 
