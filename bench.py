@@ -55,7 +55,7 @@ def main() -> None:
     ap.add_argument("--cpu-mics", type=int, default=24, help="mics of frame 0 in the CPU baseline / parity sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
-    ap.add_argument("--event-every", type=int, default=4, help="HIP events around every n-th launch group (1 = all)")
+    ap.add_argument("--event-every", type=int, default=5, help="HIP events around every n-th launch group (1 = all; 5 rotates through the 8 groups of a 64-mic frame)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -31,6 +31,7 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <type_traits>
 
 #include "engine.h"
 #include "reduce.h"
@@ -378,13 +379,31 @@ __device__ __forceinline__ bool next_candidate(const SelArgs a, const double* c,
                                int whi, double bound_h, int bound_m, double& ch, int& cm) {
   double bh = 0;
   int bm = -1;
-  for (int m = wlo + tid; m <= whi; m += kT) {
-    double hm;
-    if (!peak_mid(c, a.n, m, hm)) continue;
-    if (!(hm >= thr)) continue;
-    if (windowed && !in_window(m, a.n2, a.fs, a.med)) continue;
-    if (!higher(bound_h, bound_m, hm, m)) continue;
-    if (bm < 0 || higher(hm, m, bh, bm)) { bh = hm; bm = m; }
+  // four samples per lane and round with all twelve loads in flight (the scan is latency-bound: a dependent
+  // round trip per sample made it the longest phase of the finish kernel); plateaus take the exact slow test
+  for (int m0 = wlo + tid; m0 <= whi; m0 += 4 * kT) {
+    double xl[4], xc[4], xr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + u * kT;
+      const int mm = m <= whi ? m : whi;                       // wlo >= 1 and whi <= n - 2: all three reads are in range
+      xl[u] = c[mm - 1];
+      xc[u] = c[mm];
+      xr[u] = c[mm + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + u * kT;
+      if (m > whi) continue;
+      double hm = xc[u];
+      if (!(xl[u] < hm && xr[u] < hm)) {                       // not a strict peak: a plateau midpoint, or nothing
+        if (!(xl[u] == hm || xr[u] == hm) || !peak_mid(c, a.n, m, hm)) continue;
+      }
+      if (!(hm >= thr)) continue;
+      if (windowed && !in_window(m, a.n2, a.fs, a.med)) continue;
+      if (!higher(bound_h, bound_m, hm, m)) continue;
+      if (bm < 0 || higher(hm, m, bh, bm)) { bh = hm; bm = m; }
+    }
   }
   barg<2>(bh, bm, s, tid);
   ch = bh;
@@ -418,58 +437,68 @@ __device__ __forceinline__ int select_peaks(const SelArgs a, const double* c, in
   return count;
 }
 
-struct Stream {            // per-lane accumulators of the single pass over the row
+struct Stream {            // per-lane accumulators of the single pass over a segment
   double vmax, vmin, hb;
-  int imax, imin, mb;
+  int imax, imin, mb;      // < 0: nothing recorded yet
   double s1, s2, a1, a2;   // sums of (x-K0), (x-K0)^2, (|x|-Ka), (|x|-Ka)^2
   int below;
-  // Wavefront-uniform filters: the best maximum / minimum / peak height any lane of this wavefront has seen up to
-  // the previous tile.  Almost every sample fails all three compares and skips the bookkeeping; the filters are
-  // refreshed (three butterfly reductions) only after a tile in which some lane recorded something.
-  double bmax, bmin, bhb;
-  int dirty;
 };
 
-__device__ __forceinline__ double wave_max(double v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+// neighbour lanes through DPP wave shifts (one VALU move per dword, no LDS crossbar)
+__device__ __forceinline__ double from_lower_lane(double v) {   // lane i receives lane i - 1 (lane 0 keeps its own)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_upper_lane(double v) {   // lane i receives lane i + 1 (lane 63 keeps its own)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ void refresh_filters(Stream& t) {
-  if (__ballot(t.dirty != 0) == 0) return;
-  t.bmax = wave_max(t.imax >= 0 ? t.vmax : -INFINITY);
-  t.bmin = -wave_max(t.imin >= 0 ? -t.vmin : -INFINITY);
-  t.bhb = wave_max(t.mb >= 0 ? t.hb : -INFINITY);
-  t.dirty = 0;
-}
-
-__device__ __forceinline__ void visit(Stream& t, double x, int i, double k0, double ka) {
-  if (x > t.bmax) {                                     // first occurrence wins: strict compare inside the lane
-    if (t.imax < 0 || x > t.vmax) { t.vmax = x; t.imax = i; t.dirty = 1; }
-  }
-  if (x < t.bmin) {
-    if (t.imin < 0 || x < t.vmin) { t.vmin = x; t.imin = i; t.dirty = 1; }
-  }
-  const double d = x - k0, e = fabs(x) - ka;
+// statistics of one sample: selects instead of branches (the loop is issue-bound, and a divergent branch costs
+// more scalar bookkeeping than the handful of conditional moves it would skip).  First occurrence wins inside a
+// lane because the lane meets its samples in increasing index order.  vmax / vmin / hb start at -inf / +inf / -inf.
+template <bool FULL> __device__ __forceinline__ void visit(Stream& t, double x, int i, bool valid, double k0, double ka) {
+  const bool up = (FULL || valid) && x > t.vmax;
+  t.imax = up ? i : t.imax;
+  t.vmax = up ? x : t.vmax;
+  const bool dn = (FULL || valid) && x < t.vmin;
+  t.imin = dn ? i : t.imin;
+  t.vmin = dn ? x : t.vmin;
+  const double d = (FULL || valid) ? x - k0 : 0.0, e = (FULL || valid) ? fabs(x) - ka : 0.0;
   t.s1 += d;
-  t.s2 += d * d;
+  t.s2 = __builtin_fma(d, d, t.s2);
   t.a1 += e;
-  t.a2 += e * e;
+  t.a2 = __builtin_fma(e, e, t.a2);
 }
 
-// x at index i with neighbours l (i-1) and r (i+1): record it when it is a local maximum (plateaus: slow path)
+// x at index i with neighbours l (i-1) and r (i+1): the highest local maximum so far (scipy's floor-midpoint of a
+// plateau; inside a lane a later peak of equal height wins, as in the priority order).  `ok` carries the lane
+// mask (the outer element of lane 0 / 63 belongs to the edge pass) and, outside full tiles, the range 1 <= i <= n-2.
+// Returns true when the sample starts a plateau (r == x), which the caller resolves from memory in a rarely
+// taken branch.
+__device__ __forceinline__ bool peak_fast(Stream& t, int i, bool ok, double l, double x, double r) {
+  const bool cand = ok && l < x && x >= t.hb;
+  const bool pk = cand && r < x;
+  t.hb = pk ? x : t.hb;
+  t.mb = pk ? i : t.mb;
+  return cand && r == x;
+}
+
+__device__ __forceinline__ void peak_plateau(Stream& t, const double* c, int n, int i, double x) {
+  int q = i + 1;
+  while (q < n - 1 && c[q] == x) ++q;
+  if (!(c[q] < x)) return;
+  const int m = (i + q - 1) / 2;
+  if (t.mb < 0 || higher(x, m, t.hb, t.mb)) { t.hb = x; t.mb = m; }
+}
+
+// edge-pass form: neighbours read from memory
 __device__ __forceinline__ void peak_test(Stream& t, const double* c, int n, int i, double l, double x, double r) {
-  if (!(x >= t.bhb) || i < 1 || i > n - 2 || !(l < x)) return;   // only a peak at least as high as the best so far matters
-  int m = i;
-  if (r == x) {                                    // plateau that starts here: find its right edge in memory
-    int q = i + 1;
-    while (q < n - 1 && c[q] == x) ++q;
-    if (!(c[q] < x)) return;
-    m = (i + q - 1) / 2;
-  } else if (!(r < x)) {
-    return;
-  }
-  if (t.mb < 0 || higher(x, m, t.hb, t.mb)) { t.hb = x; t.mb = m; t.dirty = 1; }
+  if (peak_fast(t, i, i >= 1 && i <= n - 2, l, x, r)) peak_plateau(t, c, n, i, x);
 }
 
 // ------------------------------------------------------------------ 1. pivots
@@ -545,43 +574,40 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
 
   // ---- branch-free tiles of kUnroll 16-byte loads per lane, then a short guarded tail ----
   Stream t;
-  t.vmax = t.vmin = t.hb = 0;
+  t.vmax = t.hb = -INFINITY;
+  t.vmin = INFINITY;
   t.imax = t.imin = t.mb = -1;
   t.s1 = t.s2 = t.a1 = t.a2 = 0;
   t.below = 0;
-  t.bmax = t.bhb = -INFINITY;
-  t.bmin = INFINITY;
-  t.dirty = 0;
   const bool aligned = (reinterpret_cast<size_t>(c) & 15) == 0;
   const int npair = (n + 1) / 2;
   // this workgroup's share: a whole number of tiles, so segment borders fall on multiples of 128 elements
   const int per_seg = a.tiles_per_seg * kTile;
   const int p_lo = seg * per_seg < npair ? seg * per_seg : npair;
   const int p_hi = p_lo + per_seg < npair ? p_lo + per_seg : npair;
-  const int both = p_hi < n / 2 ? p_hi : n / 2;                // pairs below `both` have two valid elements
+  const int both = p_hi < (n - 1) / 2 ? p_hi : (n - 1) / 2;    // pairs below `both`: both elements valid and at most n - 2
   const int full = p_lo + (both > p_lo ? (both - p_lo) / kTile * kTile : 0);   // end of the branch-free tiles
   // Element e = 2p (+1) of pair p; lane = p % 64.  Neighbours come from the adjacent lanes; the first element
   // of lane 0 and the second of lane 63 (e % 128 == 0 / 127) are peak-tested by the edge pass below instead.
   // One tile = kUnroll element pairs per lane.  Statistics and peak tests per element; the bracket values of the
   // whole tile are appended with ONE LDS atomic per wavefront: per element a ballot gives the lane's rank
   // (mbcnt) and the wavefront's count (scalar popcount), the running scalar total is the tile's reservation.
-  auto consume_tile = [&](const double* xa, const double* xb, int pair0, bool full_tile) {
+  const bool not0 = lane != 0, not63 = lane != 63;
+  auto consume_tile = [&](const double* xa, const double* xb, int pair0, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;           // full tiles: every element valid, none at index 0 or n - 1
     int off[2 * kUnroll];
     int run = 0;
+    bool plateau = false;
 #pragma unroll
     for (int k = 0; k < kUnroll; ++k) {
       const int e0 = 2 * (pair0 + k * kTS);
-      const bool va = full_tile || e0 < n, vb = full_tile || e0 + 1 < n;
-      const double left = __shfl_up(xb[k], 1, 64);
-      const double right = __shfl_down(xa[k], 1, 64);
-      if (va) {
-        visit(t, xa[k], e0, k0, ka);
-        if (lane != 0) peak_test(t, c, n, e0, left, xa[k], xb[k]);
-      }
-      if (vb) {
-        visit(t, xb[k], e0 + 1, k0, ka);
-        if (lane != 63) peak_test(t, c, n, e0 + 1, xa[k], xb[k], right);
-      }
+      const bool va = FULL || e0 < n, vb = FULL || e0 + 1 < n;
+      const double left = from_lower_lane(xb[k]);
+      const double right = from_upper_lane(xa[k]);
+      visit<FULL>(t, xa[k], e0, va, k0, ka);
+      visit<FULL>(t, xb[k], e0 + 1, vb, k0, ka);
+      plateau |= peak_fast(t, e0, FULL ? not0 : (not0 && va && e0 >= 1 && e0 <= n - 2), left, xa[k], xb[k]);
+      plateau |= peak_fast(t, e0 + 1, FULL ? not63 : (not63 && vb && e0 + 1 <= n - 2), xa[k], xb[k], right);
       if (want_median) {
         const double ma = fabs(xa[k]), mb_ = fabs(xb[k]);
         t.below += int(va && ma < lo) + int(vb && mb_ < lo);
@@ -591,6 +617,17 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
         run += __popcll(m0);
         off[2 * k + 1] = hb_ ? run + int(__builtin_amdgcn_mbcnt_hi(unsigned(m1 >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m1), 0u))) : -1;
         run += __popcll(m1);
+      }
+    }
+    if (__ballot(plateau)) {                                   // equal neighbours somewhere in the tile: the exact, slow test
+#pragma unroll
+      for (int k = 0; k < kUnroll; ++k) {
+        const int e0 = 2 * (pair0 + k * kTS);
+        const bool va = FULL || e0 < n, vb = FULL || e0 + 1 < n;
+        const double left = from_lower_lane(xb[k]);
+        if (va && lane != 0 && e0 >= 1 && e0 <= n - 2 && left < xa[k] && xb[k] == xa[k]) peak_plateau(t, c, n, e0, xa[k]);
+        const double right = from_upper_lane(xa[k]);
+        if (vb && lane != 63 && e0 + 1 <= n - 2 && xa[k] < xb[k] && right == xb[k]) peak_plateau(t, c, n, e0 + 1, xb[k]);
       }
     }
     if (want_median && run > 0) {                              // wavefront-uniform
@@ -603,7 +640,6 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
         if (off[2 * k + 1] >= 0 && base + off[2 * k + 1] < kLoc) s.list[base + off[2 * k + 1]] = fabs(xb[k]);
       }
     }
-    refresh_filters(t);
   };
   // register double buffer: the next tile's loads are in flight while this one is consumed
   if (aligned) {
@@ -619,7 +655,7 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
       double xa[kUnroll], xb[kUnroll];
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) { xa[k] = cur[k].x; xb[k] = cur[k].y; }
-      consume_tile(xa, xb, base + tid, true);
+      consume_tile(xa, xb, base + tid, std::true_type{});
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) cur[k] = nxt[k];
     }
@@ -631,7 +667,7 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
         xa[k] = c[2 * (base + k * kTS + tid)];
         xb[k] = c[2 * (base + k * kTS + tid) + 1];
       }
-      consume_tile(xa, xb, base + tid, true);
+      consume_tile(xa, xb, base + tid, std::true_type{});
     }
   }
   if (full < p_hi) {                                           // tail: one guarded tile
@@ -642,7 +678,7 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
       xa[k] = e0 < n ? c[e0] : 0.0;
       xb[k] = e0 + 1 < n ? c[e0 + 1] : 0.0;
     }
-    consume_tile(xa, xb, full + tid, false);
+    consume_tile(xa, xb, full + tid, std::false_type{});
   }
   for (int j = tid; 2 * p_lo + 64 * j < 2 * p_hi; j += kTS) {  // edge pass: e = 128 q and e = 128 q + 127
     const int e = 2 * p_lo + (j >> 1) * 128 + ((j & 1) ? 127 : 0);
