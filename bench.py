@@ -152,11 +152,15 @@ def main() -> None:
     dom = max(entries.items(), key=lambda kv: kv[1][0]) if entries else ("none", (0.0, 0))
     dom_name, (dom_ms, dom_launches) = dom
     b_alg = algorithmic_bytes_per_pair(m, length)
-    local_pairs = args.steps * b * pairs
+    # pairs one launch of the pair pipeline processes: a step is cut into launch groups of `chunk` packed transforms
+    # (two pairs each); the events sample every args.event_every-th group, so the launch COUNT says nothing here
+    chunk = args.chunk if args.chunk > 0 else int(os.environ.get("PAL_CHUNK", "128"))
+    groups_per_step = -(-((b * pairs + 1) // 2) // chunk)
+    pairs_per_launch = b * pairs / groups_per_step
     roofline = None
     if dom_launches:
         avg_s = dom_ms * 1e-3 / dom_launches
-        achieved = b_alg * (local_pairs / dom_launches) / avg_s / 1e9
+        achieved = b_alg * pairs_per_launch / avg_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
@@ -166,8 +170,9 @@ def main() -> None:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": dom_name,
-                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": dom_launches,
-                    "algorithmic_bytes_per_pair": round(b_alg, 1), "pairs_per_launch": round(local_pairs / dom_launches, 2)}
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": dom_launches,
+                    "event_sampling": f"every {args.event_every}th launch group", "algorithmic_bytes_per_pair": round(b_alg, 1),
+                    "pairs_per_launch": round(pairs_per_launch, 2)}
 
     # ---- CPU baseline + parity sample (rank 0, N = 1 only) ---------------------------------------------
     cpu = None
@@ -197,8 +202,11 @@ def main() -> None:
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"metric run: {b} frame(s)/step/GPU x {m} mics x {length} samples @ {FS} Hz, "
-                                   f"{pairs} pairs/frame, max_expected_delay={med}, exact DFT length n={info['n']} "
-                                   f"via chirp convolution {info['m1']}x{info['m2']}",
+                                   f"{pairs} pairs/frame, max_expected_delay={med}, exact DFT length n={info['n']}"
+                                   + (f" = {info['n1']} x {info['n2']} (prime-factor inverse: in-LDS chirp convolutions of "
+                                      f"{info['tile_len']} points + dense column DFTs; forward spectra via chirp convolution "
+                                      f"{info['m1']}x{info['m2']})" if info.get("n1") else
+                                      f" via chirp convolution {info['m1']}x{info['m2']}"),
                        "frames_per_step_per_gpu": b, "mics": m, "samples": length, "pairs_per_frame": pairs,
                        "gather": gather, "parallelism": f"frames sharded over {world} GPU(s)"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels_ms": kernels,
