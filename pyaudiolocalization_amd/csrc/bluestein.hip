@@ -111,6 +111,29 @@ struct SpectrumStorer {
   }
 };
 
+// forward transform output straight into the layout of the prime-factor route (pfa.hip): SP[row][k1][k2] holds the
+// Hermitian-extended spectrum at k = CRT(k1, k2) for k1 < NR = (N1+1)/2.  Bin j < H lands at (j mod N1, j mod N2) when
+// that row is kept; its mirror n - j has the residues (N1 - k1, N2 - k2) and takes the conjugate when THAT row is
+// kept (row 0 pairs with itself and takes both).
+struct PermSpectrumStorer {
+  static constexpr const char* kName = "PermSpectrumStorer";
+  cd* SP;
+  int H, N1, N2, NR;
+  float inv1, inv2;
+  const cd* w;
+  __device__ void operator()(int g, unsigned j, cd y) const {
+    if (j >= (unsigned)H) return;
+    const cd v = cmulc(y, w[j]);
+    int k1 = int(j) - int(unsigned(float(j) * inv1)) * N1;      // j < 2^24: the float quotient is off by at most one
+    k1 = k1 < 0 ? k1 + N1 : (k1 >= N1 ? k1 - N1 : k1);
+    int k2 = int(j) - int(unsigned(float(j) * inv2)) * N2;
+    k2 = k2 < 0 ? k2 + N2 : (k2 >= N2 ? k2 - N2 : k2);
+    cd* base = SP + size_t(g) * NR * N2;
+    if (k1 < NR) base[size_t(k1) * N2 + k2] = v;
+    if (k1 == 0 ? j != 0 : k1 >= NR) base[size_t(k1 ? N1 - k1 : 0) * N2 + (k2 ? N2 - k2 : 0)] = cconj(v);
+  }
+};
+
 // inverse transform input: (R^p_k + i R^q_k) w_k over the full Hermitian-extended grid k < n
 struct PairLoader {
   static constexpr const char* kName = "PairLoader";
@@ -259,10 +282,17 @@ int Engine::forward_spectra(Plan& pl, const double* frames, size_t frame_stride,
   for (int r0 = 0; r0 < rows; r0 += chunk) {
     const int G = rows - r0 < chunk ? rows - r0 : chunk;
     FrameLoader ld{frames + size_t(r0) * frame_stride, frame_stride, len, pl.w};
-    SpectrumStorer st{spectra + size_t(r0) * pl.H, pl.H, pl.w};
     PAL_TRY(launch_cols_fwd(e, c, G, ld, W));
     PAL_TRY(launch_rows(e, c, G, W, true, 1.0));
-    PAL_TRY(launch_cols_inv(e, c, G, W, st));
+    if (pl.pfa.on()) {   // the prime-factor inverse reads the permuted layout (spec_stride() elements per row)
+      const Pfa& f = pl.pfa;
+      PermSpectrumStorer st{spectra + size_t(r0) * pl.spec_stride(), pl.H, f.n1, f.n2, f.rows(), 1.0f / float(f.n1),
+                            1.0f / float(f.n2), pl.w};
+      PAL_TRY(launch_cols_inv(e, c, G, W, st));
+    } else {
+      SpectrumStorer st{spectra + size_t(r0) * pl.H, pl.H, pl.w};
+      PAL_TRY(launch_cols_inv(e, c, G, W, st));
+    }
   }
   return PAL_OK;
 }
@@ -274,17 +304,13 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
   const Conv& c = pl.inv;
   const int n = pl.n;
   const bool pfa = pl.pfa.on();
-  const cd* permuted = nullptr;
-  if (pfa) {   // mic spectra in the (k mod N1, k mod N2) layout of pfa.hip, once per call
-    void* pp = nullptr;
-    PAL_TRY(scratch(11, size_t(nspec) * pl.pfa.rows() * pl.pfa.n2 * sizeof(cd), &pp));
-    PAL_TRY(pfa_permute(pl, spectra, nspec, static_cast<cd*>(pp), stream));
-    permuted = static_cast<const cd*>(pp);
-  }
+  const cd* permuted = spectra;   // forward_spectra wrote the (k mod N1, k mod N2) layout when the plan has the split
+  (void)nspec;
   // Launch groups alternate between two HIP streams, each with its own workspace and correlation buffer: the
   // memory-bound head and tail of one group's kernels overlap the LDS/VALU-bound middle of the other's, and the
   // peak kernel of group g runs beside the FFT passes of group g+1.  Same-slot reuse is ordered by the stream.
-  const bool two = overlap && table != nullptr;
+  const bool two = overlap == 1 && table != nullptr;
+  const bool split = overlap == 2 && table != nullptr;        // transforms on `stream`, peak selection on `stream2`
   const size_t wpoints = size_t(chunk) * (pfa ? size_t(n) : c.M());
   void* wsp = nullptr;
   PAL_TRY(scratch(0, (two ? 2 : 1) * wpoints * sizeof(cd), &wsp));
@@ -295,7 +321,7 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
   PAL_TRY(scratch(1, 2 * buf_doubles * sizeof(double), &p));
   double* cbuf = static_cast<double*>(p);
   const int64_t ntr = (npairs + 1) / 2;
-  if (two) {   // stream2 starts after everything already queued on `stream` (spectra, pair table)
+  if (two || split) {   // stream2 starts after everything already queued on `stream` (spectra, pair table)
     PAL_HIP(hipEventRecord(ev_corr[0], stream));
     PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[0], 0));
   }
@@ -304,13 +330,14 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     const int G = int(ntr - t0 < chunk ? ntr - t0 : chunk);
     const int64_t p0 = 2 * t0;
     const int rows = int(npairs - p0 < 2 * G ? npairs - p0 : 2 * G);
-    const int slot = two ? int(group & 1) : 0;
-    hipStream_t on = slot ? stream2 : stream;
+    const int slot = two || split ? int(group & 1) : 0;
+    hipStream_t on = two && slot ? stream2 : stream;
     prof_gate = prof_every <= 1 || (prof_tick++ % prof_every) == 0;
-    cd* Wg = W + size_t(slot) * wpoints;
+    cd* Wg = W + (two ? size_t(slot) * wpoints : 0);
     // odd tail with a caller buffer: the imaginary half of the last transform has no destination row there
     const bool via_scratch = !corr_out || rows < 2 * G;
     double* crow = via_scratch ? cbuf + size_t(slot) * buf_doubles : corr_out + size_t(p0) * stride;
+    if (split && group >= 2) PAL_HIP(hipStreamWaitEvent(stream, ev_peaks[slot], 0));   // group - 2 is done with this buffer
     if (pfa) {
       // sub-groups: the Y of a sub-group (1.4 MB per transform) is still in the Infinity Cache when the column
       // pass reads it back, while the peak kernels keep whole launch groups (their fixed costs want many rows)
@@ -329,11 +356,18 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     if (corr_out && via_scratch)
       PAL_HIP(hipMemcpyAsync(corr_out + size_t(p0) * stride, crow, size_t(rows) * stride * sizeof(double),
                              hipMemcpyDeviceToDevice, on));
+    hipStream_t pon = on;
+    if (split) {
+      PAL_HIP(hipEventRecord(ev_corr[slot], stream));
+      PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[slot], 0));
+      pon = stream2;
+    }
     if (table)
-      PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr, on));
+      PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr, pon));
+    if (split) PAL_HIP(hipEventRecord(ev_peaks[slot], stream2));
   }
   prof_gate = true;
-  if (two) {   // whatever follows on `stream` (downloads, the RCCL gather) sees the finished table
+  if (two || split) {   // whatever follows on `stream` (downloads, the RCCL gather) sees the finished table
     PAL_HIP(hipEventRecord(ev_peaks[0], stream2));
     PAL_HIP(hipStreamWaitEvent(stream, ev_peaks[0], 0));
   }

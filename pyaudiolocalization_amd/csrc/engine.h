@@ -56,6 +56,9 @@ struct Plan {
   Conv fwd;         // forward:  lin inputs -> H outputs
   Conv inv;         // inverse:  n inputs  -> n outputs (two real sequences per complex transform)
   Pfa pfa;          // prime-factor route of the PHAT inverse when n splits (otherwise `inv` does it)
+  // elements per row of the spectra that forward_spectra writes and pair_correlations reads: the half spectrum, or
+  // the permuted rows k1 <= (N1-1)/2 of the prime-factor layout
+  size_t spec_stride() const { return pfa.on() ? size_t(pfa.rows()) * size_t(pfa.n2) : size_t(H); }
 };
 
 struct ProfileSlot {
@@ -65,10 +68,12 @@ struct ProfileSlot {
 
 struct Engine {
   int device = 0;
+  int cu_count = 256;              // compute units of the device (persistent kernels size their grids with it)
   hipStream_t stream = nullptr;    // FFT passes, copies, everything a caller can order against
   hipStream_t stream2 = nullptr;   // peak selection of launch group g while the passes of g+1 run on `stream`
   hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams
-  bool overlap = true;             // alternate launch groups between the two streams (PAL_OVERLAP=0 turns it off)
+  int overlap = 1;                 // PAL_OVERLAP: 0 one stream; 1 launch groups alternate between the two streams;
+                                   // 2 transforms on `stream`, peak selection on `stream2`
   bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
   bool allow_pfa = true;           // PAL_PFA=0 keeps the PHAT inverse on the four-step chirp convolution
   int pfa_sub = 0;                 // transforms per row/column pass of the prime-factor route (PAL_PFA_SUB; 0 = whole group)
@@ -104,7 +109,6 @@ struct Engine {
   const cd* stage_table_compact(int ln);
   int build_pfa(Plan& pl);                  // pfa.hip: choose the split and make the tables (leaves pl.pfa off if none fits)
   void free_pfa(Pfa& f);
-  int pfa_permute(const Plan& pl, const cd* spectra, int nspec, cd* out, hipStream_t on);
   int pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, double* corr, size_t stride,
                      hipStream_t on);
   int get_plan(int n, int lin, int nout, Plan** out);

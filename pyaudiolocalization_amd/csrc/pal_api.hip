@@ -139,7 +139,7 @@ static int all_pairs_dev(Engine* e, const double* d_frames, int B, int M, int L,
   PAL_TRY(e->get_plan(2 * L - 1, L, 2 * L - 1, &pl));
   const int rows = B * M;
   void* sp = nullptr;
-  PAL_TRY(e->scratch(2, size_t(rows) * pl->H * sizeof(cd), &sp));
+  PAL_TRY(e->scratch(2, size_t(rows) * pl->spec_stride() * sizeof(cd), &sp));
   cd* spectra = static_cast<cd*>(sp);
   PAL_TRY(e->forward_spectra(*pl, d_frames, size_t(L), rows, L, spectra));
   // the pair table depends on (B, M) only: keep it on the device between calls of the same shape
@@ -177,7 +177,7 @@ static int pairs_host(Engine* e, const double* rows_in, int R, int L, const int3
   PAL_TRY(e->get_plan(2 * L - 1, L, 2 * L - 1, &pl));
   void *df = nullptr, *sp = nullptr, *dt = nullptr, *dq = nullptr;
   PAL_TRY(e->scratch(4, size_t(R) * L * sizeof(double), &df));
-  PAL_TRY(e->scratch(2, size_t(R) * pl->H * sizeof(cd), &sp));
+  PAL_TRY(e->scratch(2, size_t(R) * pl->spec_stride() * sizeof(cd), &sp));
   PAL_TRY(e->scratch(5, size_t(P) * sizeof(pal_pair_record), &dt));
   PAL_TRY(e->scratch(3, quads.size() * sizeof(int4), &dq));
   PAL_TRY(e->check(hipMemcpyAsync(df, rows_in, size_t(R) * L * sizeof(double), hipMemcpyHostToDevice, e->stream), "rows upload"));
@@ -219,10 +219,14 @@ int pal_create(int device, pal_handle* out) {
     delete e;
     return PAL_ERR_HIP;
   }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->cu_count = cus;
+  }
   const char* env = getenv("PAL_CHUNK");
   if (env && atoi(env) > 0) e->chunk = atoi(env);
   env = getenv("PAL_OVERLAP");
-  if (env) e->overlap = atoi(env) != 0;
+  if (env) e->overlap = atoi(env);
   env = getenv("PAL_RADIX3");
   if (env) e->allow_r3 = atoi(env) != 0;
   env = getenv("PAL_PFA");
@@ -347,7 +351,7 @@ static int single_pair(Engine* e, const double* sig1, int n1, const double* sig2
   PAL_TRY(e->get_plan(n, lin, n, &pl));
   void *df = nullptr, *sp = nullptr, *dc = nullptr, *dt = nullptr, *qp = nullptr, *dk = nullptr;
   PAL_TRY(e->scratch(4, size_t(2) * lin * sizeof(double), &df));
-  PAL_TRY(e->scratch(2, size_t(2) * pl->H * sizeof(cd), &sp));
+  PAL_TRY(e->scratch(2, size_t(2) * pl->spec_stride() * sizeof(cd), &sp));
   PAL_TRY(e->scratch(6, size_t(n) * sizeof(double), &dc));
   PAL_TRY(e->scratch(5, sizeof(pal_pair_record) + PAL_MAX_PEAKS * sizeof(int32_t), &dt));
   PAL_TRY(e->scratch(3, sizeof(int4), &qp));
@@ -360,7 +364,7 @@ static int single_pair(Engine* e, const double* sig1, int n1, const double* sig2
   PAL_TRY(e->check(hipStreamSynchronize(e->stream), "upload sync"));
   cd* S = static_cast<cd*>(sp);
   PAL_TRY(e->forward_spectra(*pl, d, size_t(lin), 1, n1, S));
-  PAL_TRY(e->forward_spectra(*pl, d + lin, size_t(lin), 1, n2, S + pl->H));
+  PAL_TRY(e->forward_spectra(*pl, d + lin, size_t(lin), 1, n2, S + pl->spec_stride()));
   pal_phat_params dummy{};
   PAL_TRY(e->pair_correlations(*pl, S, 2, static_cast<const int4*>(qp), 1, n2, prm ? *prm : dummy,
                                prm ? static_cast<pal_pair_record*>(dt) : nullptr,

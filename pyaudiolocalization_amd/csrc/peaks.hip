@@ -45,7 +45,8 @@ constexpr int kNW = kT / 64;
 constexpr int kTS = 256;          // lanes of the stream kernel (one segment per workgroup)
 constexpr int kNWS = kTS / 64;
 constexpr int kList = 16384;      // capacity of a row's bracket list in global memory (doubles)
-constexpr int kLoc = 2048;        // LDS capacity of one segment's share of it
+constexpr int kLoc = 3072;        // LDS capacity of one segment's share of it (a segment of 11 tiles brackets ~1100 values)
+constexpr int kMaxTilesPerSeg = 11;
 constexpr int kSample = 8192;     // block sample that places the pivots
 constexpr int kBins = 2048;       // histogram bins (sample pivots, list search, radix digits)
 constexpr int kSmall = 1024;      // exact rank search capacity
@@ -884,6 +885,7 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
   int want = (1024 + rows - 1) / rows;
   want = want < 1 ? 1 : (want > ntiles ? ntiles : want);
   a.tiles_per_seg = (ntiles + want - 1) / want;
+  if (a.tiles_per_seg > kMaxTilesPerSeg) a.tiles_per_seg = kMaxTilesPerSeg;   // the segment's bracket values must fit its LDS list
   a.splits = (ntiles + a.tiles_per_seg - 1) / a.tiles_per_seg;
   // per-stream scratch: [gcount | pre | parts | glist]; the list fills are zeroed in front of every launch
   size_t off_pre = (size_t(rows) * sizeof(int) + 127) & ~size_t(127);

@@ -18,7 +18,8 @@
 //
 // As in bluestein.hip one complex transform carries two mic pairs (real part = pair p, imaginary part = pair q)
 // and the whitened cross spectrum R = S_a conj(S_b) / (|.| + 1e-10) (utils.py:116-117) is built inside the
-// first FFT stage.  The mic spectra are kept in the permuted layout SP[mic][k1][k2], k1 <= (N1-1)/2: row N1-k1
+// first FFT stage.  The mic spectra arrive in the permuted layout SP[mic][k1][k2], k1 <= (N1-1)/2 (written by the
+// forward transform's storer, bluestein.hip PermSpectrumStorer): row N1-k1
 // is row k1 reversed and conjugated (Hermitian symmetry), so one workgroup serves both rows from the same
 // loads - tile 0 transforms x[k1, e], tile 1 the reversed row z[e] = x[N1-k1, -e], whose DFT is the reversed DFT.
 #include <cmath>
@@ -125,14 +126,6 @@ int Engine::build_pfa(Plan& pl) {
   PAL_HIP(hipStreamSynchronize(stream));       // `tab` is host memory
   pl.pfa = f;
   return PAL_OK;
-}
-
-int Engine::pfa_permute(const Plan& pl, const cd* spectra, int nspec, cd* out, hipStream_t on) {
-  const Pfa& f = pl.pfa;
-  ProfScope ps(this, "k_pfa_permute", on);
-  const int count = f.rows() * f.n2;
-  k_pfa_permute<<<dim3((count + 255) / 256, nspec), dim3(256), 0, on>>>(spectra, out, pl.n, pl.H, f.rows(), f.n2, f.e1, f.e2);
-  return check(hipGetLastError(), "k_pfa_permute");
 }
 
 int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, double* corr, size_t stride,

@@ -7,21 +7,6 @@ namespace pal {
 
 constexpr int kPfaTC = 22;   // accumulator pairs per lane of the column pass
 
-// ------------------------------------------------------------------ permuted spectra
-// SP[row][k1][k2] = full Hermitian-extended spectrum at k = (e1 k1 + e2 k2) mod n, for k1 < NR
-__global__ void k_pfa_permute(const cd* __restrict__ S, cd* __restrict__ SP, int n, int H, int NR, int N2,
-                              long long e1, long long e2) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= NR * N2) return;
-  const int k1 = idx / N2, k2 = idx - k1 * N2;
-  const long long k = (e1 * k1 + e2 * k2) % n;
-  const cd* row = S + size_t(blockIdx.y) * H;
-  cd v;
-  if (k < H) v = row[k];
-  else v = cconj(row[n - k]);
-  SP[(size_t(blockIdx.y) * NR + k1) * N2 + k2] = v;
-}
-
 // ------------------------------------------------------------------ stage functors of the row pass
 template <int LM> struct PfaHhatToLds {   // last stage of the forward FFT: times the chirp spectrum, into LDS
   static constexpr bool kLds = true;
