@@ -329,8 +329,13 @@ __device__ __forceinline__ int resolve(const double* c, int n, int dist, int tid
     for (int o = tid - (dist - 1); o <= dist - 1; o += kT) {
       if (o == 0) continue;
       const int m = p + o;
-      double hm;
-      if (peak_mid(c, n, m, hm) && higher(hm, m, h, p)) {
+      if (m < 1 || m > n - 2) continue;
+      const double xl = c[m - 1], xr = c[m + 1];             // the three reads are independent: one round trip, not three
+      double hm = c[m];
+      if (!(xl < hm && xr < hm)) {                            // not a strict peak: a plateau midpoint, or nothing
+        if (!(xl == hm || xr == hm) || !peak_mid(c, n, m, hm)) continue;
+      }
+      if (higher(hm, m, h, p)) {
         const int st = memo_find(s, m);
         if (st == 1) any_kept = 1;
         else if (st < 0 && (bm < 0 || higher(hm, m, bh, bm))) { bh = hm; bm = m; }
