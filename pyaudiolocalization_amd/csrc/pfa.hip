@@ -98,7 +98,7 @@ int Engine::build_pfa(Plan& pl) {
   PAL_SWITCH_LM(blm, k_pfa_hhat<LM><<<dim3(1), dim3(PfaLds<LM>::kLanes), 0, stream>>>(f.b, bn2, f.hhat, scale, tws));
   PAL_HIP(hipGetLastError());
   // cos / sin of 2 pi j t / N1 with the argument reduced exactly (j t mod N1) before the long-double evaluation
-  std::vector<double> tab(size_t(h > 0 ? h : 1) * f.nch * 2 * kPfaTC, 0.0);
+  std::vector<double> tab(size_t(h + kPfaUnr) * f.nch * 2 * kPfaTC, 0.0);   // kPfaUnr zero rows behind the last step
   const long double two_pi = 6.283185307179586476925286766559005768L;
   for (int j = 1; j <= h; ++j)
     for (int t = 1; t <= h; ++t) {
@@ -144,8 +144,8 @@ int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads
   {
     ProfScope ps(this, "k_pfa_cols", on);
     const unsigned nblk = unsigned(f.n2 + 63) / 64;
-    k_pfa_cols<kPfaTC><<<dim3(unsigned(G) * nblk, unsigned(f.nch + 1) / 2), dim3(256), 0, on>>>(Y, corr, stride, f.n1, f.n2, G,
-                                                                                           f.nch, f.T);
+    k_pfa_cols<kPfaTC, kPfaUnr><<<dim3(unsigned(G) * nblk, unsigned(f.nch + 3) / 4), dim3(256), 0, on>>>(Y, corr, stride, f.n1,
+                                                                                                     f.n2, G, f.nch, f.T);
     PAL_HIP(hipGetLastError());
   }
   return PAL_OK;

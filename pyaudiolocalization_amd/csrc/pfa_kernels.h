@@ -5,7 +5,8 @@
 
 namespace pal {
 
-constexpr int kPfaTC = 22;   // accumulator pairs per lane of the column pass
+constexpr int kPfaTC = 11;   // output indices t per wavefront of the column pass (x 4 accumulators each)
+constexpr int kPfaUnr = 4;   // steps j per loop iteration of the column pass (the table is padded with kPfaUnr zero rows)
 
 // ------------------------------------------------------------------ stage functors of the row pass
 template <int LM> struct PfaHhatToLds {   // last stage of the forward FFT: times the chirp spectrum, into LDS
@@ -236,58 +237,76 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
 
 // ------------------------------------------------------------------ column pass
 // One lane per column m2 (64 consecutive columns per wavefront: coalesced 1 KB loads of Y, 512 B stores of a
-// correlation row).  The four wavefronts of a workgroup split the work by role (pair p = real parts, pair q =
-// imaginary parts) and by chunk of kPfaTC output indices t; with E_j = Y_j + Y_{N1-j}, O_j = Y_j - Y_{N1-j}:
+// correlation row).  The four wavefronts of a workgroup take four chunks of kPfaTC output indices t; every
+// wavefront produces both pairs of the packed transform (pair p = real parts, pair q = imaginary parts), so a
+// cos / sin value fetched through the scalar cache feeds two FMAs.  With E_j = Y_j + Y_{N1-j}, O_j = Y_j - Y_{N1-j}:
 //   p:  c[t] = Re Y_0 + sum_j cos(j t) Re E_j - sum_j sin(j t) Im O_j,   c[N1-t] = the same with + sin
 //   q:  c[t] = Im Y_0 + sum_j cos(j t) Im E_j + sum_j sin(j t) Re O_j,   c[N1-t] = the same with - sin
-// The cos / sin rows are wave-uniform: T[(j-1)][chunk][cos | sin][tt] is read through scalar loads and feeds
-// v_fmac_f64 as a scalar operand.  The rows of Y for step j+1 are loaded before the FMAs of step j (the pass is
-// bound by memory latency, not arithmetic).
-template <int TC>
+// T[(j-1)][chunk][cos | sin][tt] is wave-uniform: scalar loads, SGPR operands of v_fmac_f64.  The pass is bound by
+// memory latency, not arithmetic: kPfaUnr steps share one batch of loads, issued one batch ahead of its FMAs.
+template <int TC, int UNR>
 __global__ __launch_bounds__(256) void k_pfa_cols(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
                                                   int N1, int N2, int G, int nch, const double* __restrict__ T) {
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
-  const int role = wave & 1, ch = int(blockIdx.y) * 2 + (wave >> 1);
+  const int ch = int(blockIdx.y) * 4 + __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
   if (ch >= nch) return;
   const int g = blockIdx.x % G, cb = blockIdx.x / G;
   const int m2 = cb * 64 + lane;
   const bool live = m2 < N2;
   const cd* Yg = Y + size_t(g) * N1 * N2 + (live ? m2 : N2 - 1);
   const int h = (N1 - 1) / 2;
-  double accC[TC], accS[TC];
+  double cx[TC], sy[TC], cy[TC], sx[TC];
 #pragma unroll
-  for (int tt = 0; tt < TC; ++tt) accC[tt] = accS[tt] = 0.0;
-  double sumE = 0.0;
+  for (int tt = 0; tt < TC; ++tt) cx[tt] = sy[tt] = cy[tt] = sx[tt] = 0.0;
+  double sumx = 0.0, sumy = 0.0;
   const double* Tj = T + size_t(ch) * 2 * TC;
   const size_t tstep = size_t(nch) * 2 * TC;
   const cd y0 = Yg[0];
-  cd yj = Yg[size_t(h > 0 ? 1 : 0) * N2], ym = Yg[size_t(h > 0 ? N1 - 1 : 0) * N2];
-  for (int j = 1; j <= h; ++j, Tj += tstep) {
-    const int jn = j < h ? j + 1 : j;                         // the last step re-reads its own rows: no branch
-    const cd nj = Yg[size_t(jn) * N2], nm = Yg[size_t(N1 - jn) * N2];
-    const double a = role ? yj.y + ym.y : yj.x + ym.x;
-    const double b = role ? yj.x - ym.x : yj.y - ym.y;
-    sumE += a;
+  cd yj[UNR], ym[UNR];
 #pragma unroll
-    for (int tt = 0; tt < TC; ++tt) {
-      accC[tt] = __builtin_fma(Tj[tt], a, accC[tt]);
-      accS[tt] = __builtin_fma(Tj[TC + tt], b, accS[tt]);
-    }
-    yj = nj;
-    ym = nm;
+  for (int u = 0; u < UNR; ++u) {
+    const int j = 1 + u <= h ? 1 + u : h;                     // (h = 0: row 0 twice, multiplied by zero table rows)
+    yj[u] = Yg[size_t(j) * N2];
+    ym[u] = Yg[size_t(h > 0 ? N1 - j : 0) * N2];
   }
-  const double base = role ? y0.y : y0.x;
+  for (int j = 1; j <= h; j += UNR) {
+    cd nj[UNR], nm[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {                           // next batch; past the end the last rows are re-read: no branch
+      const int jn = j + UNR + u <= h ? j + UNR + u : h;
+      nj[u] = Yg[size_t(jn) * N2];
+      nm[u] = Yg[size_t(N1 - jn) * N2];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u, Tj += tstep) {              // steps beyond h meet zero rows of the table
+      const bool in = j + u <= h;
+      const double ap = yj[u].x + ym[u].x, bp = yj[u].y - ym[u].y, aq = yj[u].y + ym[u].y, bq = yj[u].x - ym[u].x;
+      sumx += in ? ap : 0.0;
+      sumy += in ? aq : 0.0;
+#pragma unroll
+      for (int tt = 0; tt < TC; ++tt) {
+        const double c = Tj[tt], sn = Tj[TC + tt];
+        cx[tt] = __builtin_fma(c, ap, cx[tt]);
+        sy[tt] = __builtin_fma(sn, bp, sy[tt]);
+        cy[tt] = __builtin_fma(c, aq, cy[tt]);
+        sx[tt] = __builtin_fma(sn, bq, sx[tt]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) { yj[u] = nj[u]; ym[u] = nm[u]; }
+  }
   if (!live) return;
-  double* out = corr + size_t(2 * g + role) * stride + m2;
-  if (ch == 0) out[0] = base + sumE;
+  double* outp = corr + size_t(2 * g) * stride + m2;
+  double* outq = outp + stride;
+  if (ch == 0) { outp[0] = y0.x + sumx; outq[0] = y0.y + sumy; }
 #pragma unroll
   for (int tt = 0; tt < TC; ++tt) {
     const int t = ch * TC + tt + 1;
     if (t <= h) {
-      const double s = role ? accS[tt] : -accS[tt];
-      out[size_t(N2) * t] = base + accC[tt] + s;
-      out[size_t(N2) * (N1 - t)] = base + accC[tt] - s;
+      outp[size_t(N2) * t] = y0.x + cx[tt] - sy[tt];
+      outp[size_t(N2) * (N1 - t)] = y0.x + cx[tt] + sy[tt];
+      outq[size_t(N2) * t] = y0.y + cy[tt] + sx[tt];
+      outq[size_t(N2) * (N1 - t)] = y0.y + cy[tt] - sx[tt];
     }
   }
 }

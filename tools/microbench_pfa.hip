@@ -140,6 +140,67 @@ __global__ __launch_bounds__(256) void cols_pipe(const cd* __restrict__ Y, doubl
   }
 }
 
+// ---- column pass, both pairs in one wave: TC output indices per wave, half the table traffic per FMA
+template <int TC, int UNR>
+__global__ __launch_bounds__(256) void cols_merged(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
+                                                   int N1, int N2, int G, int nch, const double* __restrict__ T) {
+  const int lane = threadIdx.x & 63;
+  const int ch = int(blockIdx.y) * 4 + __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+  if (ch >= nch) return;
+  const int g = blockIdx.x % G, cb = blockIdx.x / G;
+  const int m2 = cb * 64 + lane;
+  const bool live = m2 < N2;
+  const cd* Yg = Y + size_t(g) * N1 * N2 + (live ? m2 : N2 - 1);
+  const int h = (N1 - 1) / 2;
+  double cx[TC], sy[TC], cy[TC], sx[TC];
+#pragma unroll
+  for (int tt = 0; tt < TC; ++tt) cx[tt] = sy[tt] = cy[tt] = sx[tt] = 0.0;
+  double sumx = 0.0, sumy = 0.0;
+  const double* Tj = T + size_t(ch) * 2 * TC;
+  const size_t tstep = size_t(nch) * 2 * TC;
+  cd yj[UNR], ym[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) { yj[u] = Yg[size_t(1 + u) * N2]; ym[u] = Yg[size_t(N1 - 1 - u) * N2]; }
+  for (int j = 1; j <= h; j += UNR) {
+    cd nj[UNR], nm[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int jn = j + UNR + u <= h ? j + UNR + u : h;
+      nj[u] = Yg[size_t(jn) * N2]; nm[u] = Yg[size_t(N1 - jn) * N2];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u, Tj += tstep) {
+      const double ap = yj[u].x + ym[u].x, bp = yj[u].y - ym[u].y, aq = yj[u].y + ym[u].y, bq = yj[u].x - ym[u].x;
+      sumx += ap; sumy += aq;
+#pragma unroll
+      for (int tt = 0; tt < TC; ++tt) {
+        const double c = Tj[tt], s = Tj[TC + tt];
+        cx[tt] = __builtin_fma(c, ap, cx[tt]);
+        sy[tt] = __builtin_fma(s, bp, sy[tt]);
+        cy[tt] = __builtin_fma(c, aq, cy[tt]);
+        sx[tt] = __builtin_fma(s, bq, sx[tt]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) { yj[u] = nj[u]; ym[u] = nm[u]; }
+  }
+  const cd y0 = Yg[0];
+  if (!live) return;
+  double* outp = corr + size_t(2 * g) * stride + m2;
+  double* outq = outp + stride;
+  if (ch == 0) { outp[0] = y0.x + sumx; outq[0] = y0.y + sumy; }
+#pragma unroll
+  for (int tt = 0; tt < TC; ++tt) {
+    const int t = ch * TC + tt + 1;
+    if (t <= h) {
+      outp[size_t(N2) * t] = y0.x + cx[tt] - sy[tt];
+      outp[size_t(N2) * (N1 - t)] = y0.x + cx[tt] + sy[tt];
+      outq[size_t(N2) * t] = y0.y + cy[tt] + sx[tt];
+      outq[size_t(N2) * (N1 - t)] = y0.y + cy[tt] - sx[tt];
+    }
+  }
+}
+
 // ---- column pass traffic only: every load of a wave in flight at once, the same stores, no arithmetic
 template <int MODE>   // 0: product layout Y[k1][N2];  1: blocked layout Y[cb][k1][64] (contiguous per workgroup)
 __global__ __launch_bounds__(256) void cols_copy(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
@@ -309,7 +370,10 @@ int main(int argc, char** argv) {
     printf("  rows launch span %.1f us\n", double(t1 - t0) / 100.0);
   }
   const dim3 cg(unsigned(G) * nblk, 1);
-  time_it("cols: product", 20, [&] { k_pfa_cols<kPfaTC><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
+  time_it("cols: product", 20, [&] { k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
+  time_it("cols: merged pairs, 11 t per wave, 1 step ahead", 20, [&] { cols_merged<11, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
+  time_it("cols: merged pairs, 11 t per wave, 2 steps/iter", 20, [&] { cols_merged<11, 2><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
+  time_it("cols: merged pairs, 11 t per wave, 4 steps/iter", 20, [&] { cols_merged<11, 4><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
   time_it("cols: traffic only, product layout", 20, [&] { cols_copy<0><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G); });
   time_it("cols: traffic only, blocked Y layout", 20, [&] { cols_copy<1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G); });
   time_it("cols: register pipeline, 1 ahead", 20, [&] { cols_pipe<22, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
@@ -342,8 +406,8 @@ int main(int argc, char** argv) {
       const int reps = 20;
       for (int i = 0; i < reps; ++i) {
         if (mode == 3 || mode == 4) {
-          k_pfa_cols<kPfaTC><<<cg, dim3(256), 0, sa>>>(Y, corr, stride, N1, N2, G, nch, T);
-          k_pfa_cols<kPfaTC><<<cg, dim3(256), 0, mode == 4 ? sb : sa>>>(Y2, corr2, stride, N1, N2, G, nch, T);
+          k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, sa>>>(Y, corr, stride, N1, N2, G, 4, T);
+          k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, mode == 4 ? sb : sa>>>(Y2, corr2, stride, N1, N2, G, 4, T);
         } else {
           k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, sa>>>(a);
           k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, mode == 6 ? sb : sa>>>(a2);
@@ -360,7 +424,7 @@ int main(int argc, char** argv) {
       const int reps = 20;
       for (int i = 0; i < reps; ++i) {
         if (mode != 1) k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, sa>>>(a2);
-        if (mode != 0) k_pfa_cols<kPfaTC><<<cg, dim3(256), 0, mode == 2 ? sb : sa>>>(Y, corr, stride, N1, N2, G, nch, T);
+        if (mode != 0) k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, mode == 2 ? sb : sa>>>(Y, corr, stride, N1, N2, G, 4, T);
       }
       CHECK(hipDeviceSynchronize());
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
