@@ -309,29 +309,31 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
   // Launch groups alternate between two HIP streams, each with its own workspace and correlation buffer: the
   // memory-bound head and tail of one group's kernels overlap the LDS/VALU-bound middle of the other's, and the
   // peak kernel of group g runs beside the FFT passes of group g+1.  Same-slot reuse is ordered by the stream.
-  const bool two = overlap == 1 && table != nullptr;
+  const bool two = (overlap == 1 || overlap == 3) && table != nullptr;
+  const int nslot = two ? (overlap == 3 ? 3 : 2) : 1;
   const bool split = overlap == 2 && table != nullptr;        // transforms on `stream`, peak selection on `stream2`
   const size_t wpoints = size_t(chunk) * (pfa ? size_t(n) : c.M());
   void* wsp = nullptr;
-  PAL_TRY(scratch(0, (two ? 2 : 1) * wpoints * sizeof(cd), &wsp));
+  PAL_TRY(scratch(0, size_t(nslot) * wpoints * sizeof(cd), &wsp));
   cd* W = static_cast<cd*>(wsp);
   const size_t stride = corr_out ? size_t(n) : (size_t(n) + 1) & ~size_t(1);
   const size_t buf_doubles = size_t(2 * chunk) * stride;
   void* p = nullptr;
-  PAL_TRY(scratch(1, 2 * buf_doubles * sizeof(double), &p));
+  PAL_TRY(scratch(1, size_t(nslot > 2 ? nslot : 2) * buf_doubles * sizeof(double), &p));
   double* cbuf = static_cast<double*>(p);
   const int64_t ntr = (npairs + 1) / 2;
-  if (two || split) {   // stream2 starts after everything already queued on `stream` (spectra, pair table)
+  if (two || split) {   // the other streams start after everything already queued on `stream` (spectra, pair table)
     PAL_HIP(hipEventRecord(ev_corr[0], stream));
     PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[0], 0));
+    if (nslot == 3) PAL_HIP(hipStreamWaitEvent(stream3, ev_corr[0], 0));
   }
   int64_t group = 0;
   for (int64_t t0 = 0; t0 < ntr; t0 += chunk, ++group) {
     const int G = int(ntr - t0 < chunk ? ntr - t0 : chunk);
     const int64_t p0 = 2 * t0;
     const int rows = int(npairs - p0 < 2 * G ? npairs - p0 : 2 * G);
-    const int slot = two || split ? int(group & 1) : 0;
-    hipStream_t on = two && slot ? stream2 : stream;
+    const int slot = two ? int(group % nslot) : (split ? int(group & 1) : 0);
+    hipStream_t on = two ? (slot == 0 ? stream : (slot == 1 ? stream2 : stream3)) : stream;
     prof_gate = prof_every <= 1 || (prof_tick++ % prof_every) == 0;
     cd* Wg = W + (two ? size_t(slot) * wpoints : 0);
     // odd tail with a caller buffer: the imaginary half of the last transform has no destination row there
@@ -370,6 +372,10 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
   if (two || split) {   // whatever follows on `stream` (downloads, the RCCL gather) sees the finished table
     PAL_HIP(hipEventRecord(ev_peaks[0], stream2));
     PAL_HIP(hipStreamWaitEvent(stream, ev_peaks[0], 0));
+    if (nslot == 3) {
+      PAL_HIP(hipEventRecord(ev_join3, stream3));
+      PAL_HIP(hipStreamWaitEvent(stream, ev_join3, 0));
+    }
   }
   return PAL_OK;
 }

@@ -70,10 +70,12 @@ struct Engine {
   int device = 0;
   int cu_count = 256;              // compute units of the device (persistent kernels size their grids with it)
   hipStream_t stream = nullptr;    // FFT passes, copies, everything a caller can order against
-  hipStream_t stream2 = nullptr;   // peak selection of launch group g while the passes of g+1 run on `stream`
+  hipStream_t stream2 = nullptr;   // second launch-group slot (or the peak selection in PAL_OVERLAP=2)
+  hipStream_t stream3 = nullptr;   // third launch-group slot (PAL_OVERLAP=3)
+  hipEvent_t ev_join3 = nullptr;
   hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams
   int overlap = 1;                 // PAL_OVERLAP: 0 one stream; 1 launch groups alternate between the two streams;
-                                   // 2 transforms on `stream`, peak selection on `stream2`
+                                   // 2 transforms on `stream`, peak selection on `stream2`; 3 groups rotate over three streams
   bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
   bool allow_pfa = true;           // PAL_PFA=0 keeps the PHAT inverse on the four-step chirp convolution
   int pfa_sub = 0;                 // transforms per row/column pass of the prime-factor route (PAL_PFA_SUB; 0 = whole group)

@@ -32,6 +32,7 @@ int Engine::scratch(int idx, size_t bytes, void** out) {
     if (ws[idx]) {                       // either stream may still be using the old block
       PAL_HIP(hipStreamSynchronize(stream));
       PAL_HIP(hipStreamSynchronize(stream2));
+      PAL_HIP(hipStreamSynchronize(stream3));
       PAL_HIP(hipFree(ws[idx]));
       ws[idx] = nullptr;
       ws_bytes[idx] = 0;
@@ -67,6 +68,7 @@ void Engine::prof_begin(int, hipEvent_t* a, hipStream_t on) {
   if (pending.size() >= 16384) {
     hipStreamSynchronize(stream);
     hipStreamSynchronize(stream2);
+    hipStreamSynchronize(stream3);
     prof_flush();
   }
   *a = take_event(this);
@@ -211,6 +213,8 @@ int pal_create(int device, pal_handle* out) {
   e->device = device;
   if ((rc = hipSetDevice(device)) != hipSuccess || (rc = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
       (rc = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking)) != hipSuccess ||
+      (rc = hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking)) != hipSuccess ||
+      (rc = hipEventCreateWithFlags(&e->ev_join3, hipEventDisableTiming)) != hipSuccess ||
       (rc = hipEventCreateWithFlags(&e->ev_corr[0], hipEventDisableTiming)) != hipSuccess ||
       (rc = hipEventCreateWithFlags(&e->ev_corr[1], hipEventDisableTiming)) != hipSuccess ||
       (rc = hipEventCreateWithFlags(&e->ev_peaks[0], hipEventDisableTiming)) != hipSuccess ||
@@ -256,6 +260,8 @@ void pal_destroy(pal_handle h) {
   for (hipEvent_t ev : e->ev_pool) hipEventDestroy(ev);
   for (int k = 0; k < 2; ++k) { hipEventDestroy(e->ev_corr[k]); hipEventDestroy(e->ev_peaks[k]); }
   hipStreamDestroy(e->stream2);
+  hipStreamDestroy(e->stream3);
+  hipEventDestroy(e->ev_join3);
   hipStreamDestroy(e->stream);
   delete e;
 }

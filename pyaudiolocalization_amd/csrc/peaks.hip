@@ -898,7 +898,7 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
   size_t off_list = (off_parts + size_t(rows) * a.splits * sizeof(Partial) + 127) & ~size_t(127);
   const size_t total = off_list + (a.method == 0 ? size_t(rows) * kList * sizeof(double) : 0);
   void* sp = nullptr;
-  PAL_TRY(scratch(on == stream2 ? 9 : 8, total, &sp));
+  PAL_TRY(scratch(on == stream2 ? 9 : (on == stream3 ? 12 : 8), total, &sp));
   char* base = static_cast<char*>(sp);
   a.gcount = reinterpret_cast<int*>(base);
   a.pre = reinterpret_cast<RowPre*>(base + off_pre);

@@ -374,6 +374,10 @@ int main(int argc, char** argv) {
   time_it("cols: merged pairs, 11 t per wave, 1 step ahead", 20, [&] { cols_merged<11, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
   time_it("cols: merged pairs, 11 t per wave, 2 steps/iter", 20, [&] { cols_merged<11, 2><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
   time_it("cols: merged pairs, 11 t per wave, 4 steps/iter", 20, [&] { cols_merged<11, 4><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
+  time_it("cols: merged pairs, 11 t per wave, 8 steps/iter", 20, [&] { cols_merged<11, 8><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
+  time_it("cols: merged pairs, 22 t per wave, 2 steps/iter", 20, [&] { cols_merged<22, 2><<<dim3(unsigned(G) * nblk, 1), dim3(128)>>>(Y, corr, stride, N1, N2, G, 2, T); });
+  time_it("cols: merged pairs, 22 t per wave, 4 steps/iter", 20, [&] { cols_merged<22, 4><<<dim3(unsigned(G) * nblk, 1), dim3(128)>>>(Y, corr, stride, N1, N2, G, 2, T); });
+  time_it("cols: merged pairs, 6 t per wave, 4 steps/iter", 20, [&] { cols_merged<6, 4><<<dim3(unsigned(G) * nblk, 2), dim3(256)>>>(Y, corr, stride, N1, N2, G, 8, T); });
   time_it("cols: traffic only, product layout", 20, [&] { cols_copy<0><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G); });
   time_it("cols: traffic only, blocked Y layout", 20, [&] { cols_copy<1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G); });
   time_it("cols: register pipeline, 1 ahead", 20, [&] { cols_pipe<22, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, nch, T); });
