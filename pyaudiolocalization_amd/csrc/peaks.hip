@@ -451,16 +451,16 @@ struct Stream {            // per-lane accumulators of the single pass over a se
 };
 
 // neighbour lanes through DPP wave shifts (one VALU move per dword, no LDS crossbar)
-__device__ __forceinline__ double from_lower_lane(double v) {   // lane i receives lane i - 1 (lane 0 keeps its own)
+__device__ __forceinline__ double from_lower_lane(double v) {   // lane i receives lane i - 1 (lane 0: zero, never used)
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x138, 0xf, 0xf, true);           // wave_shr:1 (no `old` operand: no copy in front)
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x138, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double from_upper_lane(double v) {   // lane i receives lane i + 1 (lane 63 keeps its own)
+__device__ __forceinline__ double from_upper_lane(double v) {   // lane i receives lane i + 1 (lane 63: zero, never used)
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x130, 0xf, 0xf, true);           // wave_shl:1
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x130, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 
