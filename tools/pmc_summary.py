@@ -16,7 +16,7 @@ out = sys.argv[2] if len(sys.argv) > 2 else None
 def bench_name(kernel):
     k = kernel.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("pal::", "")
     k = re.sub(r"k_pfa_rows<(\d+), false>", r"k_pfa_rows<\1>", k)
-    k = re.sub(r"k_pfa_cols<\d+>", "k_pfa_cols", k)
+    k = re.sub(r"k_pfa_cols<[\d, ]+>", "k_pfa_cols", k)
     k = re.sub(r"k_rows<(\d+), true>", r"k_rows<\1,conv>", k)
     k = re.sub(r"k_rows<(\d+), false>", r"k_rows<\1,fwd>", k)
     return k.replace(", ", ",")
