@@ -167,6 +167,16 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
   }
   stamp();
 
+  // the sixteen chirp-spectrum values of this lane's seam butterfly: requested now, used after the middle stages
+  // (the registers are free: LDS, not the register file, limits this kernel to two wavefronts per SIMD)
+  cd hh[16];
+  {
+    const int i = tid % NB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hh[r] = a.hhat[i + NB * r];
+    asm volatile("" ::: "memory");                            // keep the loads here (the scheduler would sink them to their use)
+  }
+
   // ---- 2. forward middle stages
   wg_fft_middle<LM, false, false, 4, 2, CT>(data, tw, tid);
   stamp();
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
       const int k = i + NB * q;                               // < P: butterfly of the last stage, outputs k + P r
       stage_load<LM, false, false, LPL, 2, CT>(tile, tw, t * P + k, v);
 #pragma unroll
-      for (int r = 0; r < RL; ++r) u[q + SPLIT * r] = cmul(v[r], a.hhat[k + P * r]);
+      for (int r = 0; r < RL; ++r) u[q + SPLIT * r] = cmul(v[r], hh[q + SPLIT * r]);   // element k + P r = i + NB (q + SPLIT r)
     }
     __syncthreads();                                          // every lane has read its inputs
     dft16<true>(u);
@@ -196,19 +206,19 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
   //         scaled by the chirp b[e] and by the column twiddle exp(2 pi i u1 row m2 / N1) and stored at Y[row][m2]
   //         (tile 0: row k1, m2 = e; tile 1: row N1 - k1 of the reversed transform, m2 = -e mod N2).  The twiddle
   //         index u1 row m2 mod N1 advances by a wave-uniform step from one output of a butterfly to the next.
-  wg_fft_middle<LM, false, true, 4, 2, CT>(data, tw, tid);
   {
-    constexpr int LPL = stage_tw_last(LM), RL = stage_radix(LM, LPL), P = 1 << LPL, PER = 16 / RL;
+    constexpr int LPL = stage_tw_last(LM), RL = stage_radix(LM, LPL), P = 1 << LPL, PER = 16 / RL, HR = RL / 2;
     cd* const Yg = a.Y + size_t(g) * a.N1 * a.N2;
     const int N1 = a.N1, N2 = a.N2;
     const int kr = k1 ? N1 - k1 : 0;
+    // chirp and column-twiddle factors of this lane's outputs: requested before the inverse middle stages, which touch
+    // only LDS, so that they have landed when the last stage needs them
+    cd fb[PER][HR], fr[PER][HR];
+    int m2s[PER][HR];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int w = tid + L::kLanes * q;
       const int t = __builtin_amdgcn_readfirstlane(w / P), k = w % P;   // tile (wave-uniform), butterfly
-      cd v[RL];
-      stage_load<LM, false, true, LPL, 2, CT>(tile, tw, w, v);
-      if (t == 1 && k1 == 0) continue;                                  // row 0 pairs with itself: tile 1 is a duplicate
       const int row = t ? kr : k1;
       const int2 rt = a.rowtab[row];                                    // scalar: u1 row mod N1 and the index step between outputs
       const unsigned uk = unsigned(rt.x), step = unsigned(rt.y), n1 = unsigned(N1);
@@ -217,18 +227,35 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
       unsigned idx = x - __umul24(unsigned(float(x) * a.inv), n1);      // x mod N1, off by at most one N1 either way
       idx = min(idx, idx + n1);                                         // (unsigned wrap-around picks the in-range value)
       idx = min(idx, idx - n1);
-      cd* const Yrow = Yg + size_t(row) * N2;
 #pragma unroll
-      for (int r = 0; r < RL / 2; ++r) {
+      for (int r = 0; r < HR; ++r) {
         const int e = k + P * r;
         const int ee = e < N2 ? e : N2 - 1;
         int m2 = t ? mb - P * r : e;
         unsigned ti = idx;
         if (t && e == 0) { m2 = 0; ti = 0; }
-        const cd z = cmulc(cmul(v[r], a.b[ee]), a.r1[ti]);              // r1 holds exp(-2 pi i q / N1)
-        if (e < N2) Yrow[m2] = z;
+        m2s[q][r] = m2;
+        fb[q][r] = a.b[ee];
+        fr[q][r] = a.r1[ti];                                            // r1 holds exp(-2 pi i q / N1)
         if (t) { idx -= step; idx = min(idx, idx + n1); }
         else { idx += step; idx = min(idx, idx - n1); }
+      }
+    }
+    asm volatile("" ::: "memory");                                      // keep these loads above the LDS-only stages
+    wg_fft_middle<LM, false, true, 4, 2, CT>(data, tw, tid);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int w = tid + L::kLanes * q;
+      const int t = __builtin_amdgcn_readfirstlane(w / P), k = w % P;
+      cd v[RL];
+      stage_load<LM, false, true, LPL, 2, CT>(tile, tw, w, v);
+      if (t == 1 && k1 == 0) continue;                                  // row 0 pairs with itself: tile 1 is a duplicate
+      cd* const Yrow = Yg + size_t(t ? kr : k1) * N2;
+#pragma unroll
+      for (int r = 0; r < HR; ++r) {
+        const int e = k + P * r;
+        const cd z = cmulc(cmul(v[r], fb[q][r]), fr[q][r]);
+        if (e < N2) Yrow[m2s[q][r]] = z;
       }
     }
   }
