@@ -39,6 +39,7 @@ template <int LM> struct PfaLds {         // LDS sizes of the row pass
   static constexpr bool kCompact = LM >= 11;
   static constexpr int kM = 1 << LM, kLanes = 2 * kM / 16;
   static constexpr int kTw = kCompact ? stage_twc_size(LM) : stage_tw_size(LM);
+  static constexpr int kTwPad = (kTw + kLanes - 1) / kLanes * kLanes;   // whole rounds of the workgroup: an unguarded copy
 };
 
 template <int LM>
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
   constexpr bool CT = L::kCompact;
   static_assert(stage_log2r(LM, 0) == 4, "the hand-mapped stages assume a radix-16 first stage");
   __shared__ cd data[2 * M];
-  __shared__ cd tw_lds[TWG ? 1 : L::kTw];
+  __shared__ cd tw_lds[TWG ? 1 : L::kTwPad];
   const cd* const tw = TWG ? a.tws : tw_lds;
   const int tid = threadIdx.x;
   const int g = blockIdx.x % a.G, k1 = blockIdx.x / a.G;
@@ -107,20 +108,20 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
     ++stamp_at;
   };
   stamp();
-  // the twiddle rows travel global -> registers -> LDS; their loads are issued first and land while the pair
-  // table and the spectrum rows are being fetched
-  constexpr int kTwPer = TWG ? 0 : (L::kTw + L::kLanes - 1) / L::kLanes;
+  // the twiddle rows travel global -> registers -> LDS.  Their loads are issued first (the table is allocated to
+  // 2^LM entries, so whole rounds need no guard: a guarded copy made the compiler wait for ALL outstanding loads
+  // four times) and land while the pair table and the spectrum rows are being fetched.
+  constexpr int kTwPer = TWG ? 0 : L::kTwPad / L::kLanes;
   cd twr[kTwPer + 1];
 #pragma unroll
-  for (int q = 0; q < kTwPer; ++q) {
-    const int idx = tid + q * L::kLanes;
-    twr[q] = a.tws[idx < L::kTw ? idx : L::kTw - 1];
-  }
+  for (int q = 0; q < kTwPer; ++q) twr[q] = a.tws[tid + q * L::kLanes];
   const LdsTile<LM, false, 2> tile{data};
 
   // ---- 1. first forward stage
   {
-    const int4 q = a.quad[g];
+    // (constant address space: a uniform entry of a table nobody writes -> scalar load, not a vector load + wait)
+    const auto* qp = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.quad)) + 4 * g;
+    const int4 q = make_int4(qp[0], qp[1], qp[2], qp[3]);
     const size_t mic = size_t(a.NR) * a.N2, off = size_t(k1) * a.N2;
     const bool second = q.z >= 0;
     const cd* sa = a.SP + size_t(q.x) * mic + off;
@@ -139,10 +140,7 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
       ch[u] = a.b[ee];
     }
 #pragma unroll
-    for (int q = 0; q < kTwPer; ++q) {
-      const int idx = tid + q * L::kLanes;
-      if (idx < L::kTw) tw_lds[idx] = twr[q];
-    }
+    for (int q = 0; q < kTwPer; ++q) tw_lds[tid + q * L::kLanes] = twr[q];
     // Lower lanes (tile 0) whiten inputs r = 0..3 of butterfly i, upper lanes (tile 1) r = 4..7.  Each lane forms its
     // own tile's value `own` and the other tile's value `oth` of the same bin: with sg = +1 / -1 for tile 0 / 1
     //   tile 0: R^p + i R^q,  tile 1: conj(R^p) + i conj(R^q)   =>   own = (r1.x - sg r2.y, sg r1.y + r2.x), oth = own(-sg)
@@ -220,8 +218,9 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
       const int w = tid + L::kLanes * q;
       const int t = __builtin_amdgcn_readfirstlane(w / P), k = w % P;   // tile (wave-uniform), butterfly
       const int row = t ? kr : k1;
-      const int2 rt = a.rowtab[row];                                    // scalar: u1 row mod N1 and the index step between outputs
-      const unsigned uk = unsigned(rt.x), step = unsigned(rt.y), n1 = unsigned(N1);
+      // scalar load (constant address space): u1 row mod N1 and the index step between outputs
+      const auto* rt = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.rowtab)) + 2 * row;
+      const unsigned uk = unsigned(rt[0]), step = unsigned(rt[1]), n1 = unsigned(N1);
       const int mb = t ? N2 - k : k;                                    // m2 of output r is mb -/+ P r (tile 1: except e = 0)
       const unsigned x = __umul24(uk, unsigned(mb));                    // < 2^24: exact in float
       unsigned idx = x - __umul24(unsigned(float(x) * a.inv), n1);      // x mod N1, off by at most one N1 either way
