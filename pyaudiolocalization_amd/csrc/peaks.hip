@@ -507,6 +507,14 @@ __device__ __forceinline__ void peak_test(Stream& t, const double* c, int n, int
   if (peak_fast(t, i, i >= 1 && i <= n - 2, l, x, r)) peak_plateau(t, c, n, i, x);
 }
 
+// one row's parameters through the scalar cache (uniform address, written by the previous launch)
+__device__ __forceinline__ RowPre load_pre(const RowPre* pre, int row) {
+  const auto* p = reinterpret_cast<const __attribute__((address_space(4))) double*>(reinterpret_cast<uintptr_t>(pre)) + 4 * size_t(row);
+  RowPre r;
+  r.k0 = p[0]; r.ka = p[1]; r.lo = p[2]; r.hi = p[3];
+  return r;
+}
+
 // ------------------------------------------------------------------ 1. pivots
 // block sample (16 coalesced runs of 512 samples spread over the row): shifts for the one-pass variances and
 // the pivots that bracket the median
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
   const double* c = a.corr + size_t(row) * a.stride;
   const int n = a.n;
   const bool want_median = a.method == 0;
-  const RowPre pre = a.pre[row];
+  const RowPre pre = load_pre(a.pre, row);
   const double k0 = pre.k0, ka = pre.ka, lo = pre.lo, hi = pre.hi;
   if (tid == 0) s.count = 0;
   __syncthreads();
@@ -725,7 +733,7 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   const double* c = a.corr + size_t(row) * a.stride;
   const int n = a.n;
   const bool want_median = a.method == 0;
-  const RowPre pre = a.pre[row];
+  const RowPre pre = load_pre(a.pre, row);
   const double k0 = pre.k0, ka = pre.ka, lo = pre.lo, hi = pre.hi;
   const unsigned r1 = unsigned((n - 1) / 2), r2 = unsigned(n / 2);   // ranks of the median's one or two order statistics
 
