@@ -128,6 +128,22 @@ template <int T> struct Cols3FromGlobal {
   }
 };
 
+// stage-major twiddle table of a 2^LN-point sub-transform: global -> registers -> LDS with every load in flight
+// before the first store (a guarded element-wise copy makes the compiler wait for ALL outstanding loads once per
+// round).  The device table and the LDS array both hold 2^LN entries (>= stage_tw_size(LN)).
+template <int LN, int LANES> __device__ __forceinline__ void copy_tw(cd* tw, const cd* __restrict__ tws, int tid) {
+  constexpr int N = 1 << LN;
+  if constexpr (N % LANES == 0) {
+    cd r[N / LANES];
+#pragma unroll
+    for (int q = 0; q < N / LANES; ++q) r[q] = tws[tid + q * LANES];
+#pragma unroll
+    for (int q = 0; q < N / LANES; ++q) tw[tid + q * LANES] = r[q];
+  } else {
+    for (int i = tid; i < stage_tw_size(LN); i += LANES) tw[i] = tws[i];
+  }
+}
+
 // ------------------------------------------------------------------ the three passes (M1 = 2^L1)
 // Each workgroup (256 lanes) owns 4096 points.  Grid = G * M / 4096, transform index fastest so that
 // the workgroups that share chirp-spectrum rows and twiddles run together.
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(256) void k_cols_fwd(Loader ld, cd* __restrict__ W,
   const int tid = threadIdx.x;
   const int g = blockIdx.x % G;
   const unsigned c0 = (blockIdx.x / G) * T;
-  for (int i = tid; i < stage_tw_size(L1); i += kLanes) tw[i] = tws[i];
+  copy_tw<L1, kLanes>(tw, tws, tid);
   wg_fft<L1, true, false, T>(data, tw, tid, ColsFromLoader<Loader>{ld, g, l2, c0},
                              ColsToGlobal{W + (size_t(g) << (L1 + l2)), l2, c0, twA, twB});
 }
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(256) void k_rows(cd* __restrict__ W, const cd* __re
   const int tid = threadIdx.x;
   const int g = blockIdx.x % G;
   const size_t tile = blockIdx.x / G;                       // 4096 consecutive points = 4096/N2 rows
-  for (int i = tid; i < stage_tw_size(L2); i += kLanes) tw[i] = tws[i];
+  copy_tw<L2, kLanes>(tw, tws, tid);
   cd* base = W + size_t(g) * m + tile * kPoints;
   if (CONV) {
     wg_fft<L2, false, false, T>(data, tw, tid, RowsGlobal<L2>{base}, RowsChatToLds<L2>{data, chat + tile * kPoints});
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(256) void k_cols_inv(const cd* __restrict__ W, Stor
   const int tid = threadIdx.x;
   const int g = blockIdx.x % G;
   const unsigned c0 = (blockIdx.x / G) * T;
-  for (int i = tid; i < stage_tw_size(L1); i += kLanes) tw[i] = tws[i];
+  copy_tw<L1, kLanes>(tw, tws, tid);
   wg_fft<L1, true, true, T>(data, tw, tid, ColsFromGlobal{W + (size_t(g) << (L1 + l2)), l2, c0, twA, twB},
                             ColsToStorer<Storer>{st, g, l2, c0});
 }
