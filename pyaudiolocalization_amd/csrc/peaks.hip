@@ -494,17 +494,18 @@ __device__ __forceinline__ bool peak_fast(Stream& t, int i, bool ok, double l, d
   return cand && r == x;
 }
 
-__device__ __forceinline__ void peak_plateau(Stream& t, const double* c, int n, int i, double x) {
+// plateau that starts at absolute index i: find its right edge in memory; indices are recorded relative to `lane_off`
+__device__ __forceinline__ void peak_plateau(Stream& t, const double* c, int n, int i, double x, int lane_off) {
   int q = i + 1;
   while (q < n - 1 && c[q] == x) ++q;
   if (!(c[q] < x)) return;
-  const int m = (i + q - 1) / 2;
+  const int m = (i + q - 1) / 2 - lane_off;
   if (t.mb < 0 || higher(x, m, t.hb, t.mb)) { t.hb = x; t.mb = m; }
 }
 
 // edge-pass form: neighbours read from memory
-__device__ __forceinline__ void peak_test(Stream& t, const double* c, int n, int i, double l, double x, double r) {
-  if (peak_fast(t, i, i >= 1 && i <= n - 2, l, x, r)) peak_plateau(t, c, n, i, x);
+__device__ __forceinline__ void peak_test(Stream& t, const double* c, int n, int i, double l, double x, double r, int lane_off) {
+  if (peak_fast(t, i - lane_off, i >= 1 && i <= n - 2, l, x, r)) peak_plateau(t, c, n, i, x, lane_off);
 }
 
 // one row's parameters through the scalar cache (uniform address, written by the previous launch)
@@ -607,21 +608,25 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
   // whole tile are appended with ONE LDS atomic per wavefront: per element a ballot gives the lane's rank
   // (mbcnt) and the wavefront's count (scalar popcount), the running scalar total is the tile's reservation.
   const bool not0 = lane != 0, not63 = lane != 63;
-  auto consume_tile = [&](const double* xa, const double* xb, int pair0, auto full_tag) {
+  auto consume_tile = [&](const double* xa, const double* xb, int pair0u, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;           // full tiles: every element valid, none at index 0 or n - 1
+    const int pair0 = pair0u + tid;                            // pair0u: the tile's first pair (wave-uniform)
     int off[2 * kUnroll];
     int run = 0;
     bool plateau = false;
 #pragma unroll
     for (int k = 0; k < kUnroll; ++k) {
       const int e0 = 2 * (pair0 + k * kTS);
+      // indices are recorded relative to the lane's own offset 2 tid: the recorded value is wave-uniform (a scalar
+      // operand of the select instead of a vector add per sample); the lane offset is added back after the loop
+      const int u0 = 2 * (pair0u + k * kTS);
       const bool va = FULL || e0 < n, vb = FULL || e0 + 1 < n;
       const double left = from_lower_lane(xb[k]);
       const double right = from_upper_lane(xa[k]);
-      visit<FULL>(t, xa[k], e0, va, k0, ka);
-      visit<FULL>(t, xb[k], e0 + 1, vb, k0, ka);
-      plateau |= peak_fast(t, e0, FULL ? not0 : (not0 && va && e0 >= 1 && e0 <= n - 2), left, xa[k], xb[k]);
-      plateau |= peak_fast(t, e0 + 1, FULL ? not63 : (not63 && vb && e0 + 1 <= n - 2), xa[k], xb[k], right);
+      visit<FULL>(t, xa[k], u0, va, k0, ka);
+      visit<FULL>(t, xb[k], u0 + 1, vb, k0, ka);
+      plateau |= peak_fast(t, u0, FULL ? not0 : (not0 && va && e0 >= 1 && e0 <= n - 2), left, xa[k], xb[k]);
+      plateau |= peak_fast(t, u0 + 1, FULL ? not63 : (not63 && vb && e0 + 1 <= n - 2), xa[k], xb[k], right);
       if (want_median) {
         const double ma = fabs(xa[k]), mb_ = fabs(xb[k]);
         t.below += int(va && ma < lo) + int(vb && mb_ < lo);
@@ -639,9 +644,9 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
         const int e0 = 2 * (pair0 + k * kTS);
         const bool va = FULL || e0 < n, vb = FULL || e0 + 1 < n;
         const double left = from_lower_lane(xb[k]);
-        if (va && lane != 0 && e0 >= 1 && e0 <= n - 2 && left < xa[k] && xb[k] == xa[k]) peak_plateau(t, c, n, e0, xa[k]);
+        if (va && lane != 0 && e0 >= 1 && e0 <= n - 2 && left < xa[k] && xb[k] == xa[k]) peak_plateau(t, c, n, e0, xa[k], 2 * tid);
         const double right = from_upper_lane(xa[k]);
-        if (vb && lane != 63 && e0 + 1 <= n - 2 && xa[k] < xb[k] && right == xb[k]) peak_plateau(t, c, n, e0 + 1, xb[k]);
+        if (vb && lane != 63 && e0 + 1 <= n - 2 && xa[k] < xb[k] && right == xb[k]) peak_plateau(t, c, n, e0 + 1, xb[k], 2 * tid);
       }
     }
     if (want_median && run > 0) {                              // wavefront-uniform
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
       double xa[kUnroll], xb[kUnroll];
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) { xa[k] = cur[k].x; xb[k] = cur[k].y; }
-      consume_tile(xa, xb, base + tid, std::true_type{});
+      consume_tile(xa, xb, base, std::true_type{});
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) cur[k] = nxt[k];
     }
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
         xa[k] = c[2 * (base + k * kTS + tid)];
         xb[k] = c[2 * (base + k * kTS + tid) + 1];
       }
-      consume_tile(xa, xb, base + tid, std::true_type{});
+      consume_tile(xa, xb, base, std::true_type{});
     }
   }
   if (full < p_hi) {                                           // tail: one guarded tile
@@ -692,14 +697,14 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
       xa[k] = e0 < n ? c[e0] : 0.0;
       xb[k] = e0 + 1 < n ? c[e0 + 1] : 0.0;
     }
-    consume_tile(xa, xb, full + tid, std::false_type{});
+    consume_tile(xa, xb, full, std::false_type{});
   }
   for (int j = tid; 2 * p_lo + 64 * j < 2 * p_hi; j += kTS) {  // edge pass: e = 128 q and e = 128 q + 127
     const int e = 2 * p_lo + (j >> 1) * 128 + ((j & 1) ? 127 : 0);
-    if (e >= 1 && e <= n - 2 && e < 2 * p_hi) peak_test(t, c, n, e, c[e - 1], c[e], c[e + 1]);
+    if (e >= 1 && e <= n - 2 && e < 2 * p_hi) peak_test(t, c, n, e, c[e - 1], c[e], c[e + 1], 2 * tid);
   }
   double vmax = t.vmax, vmin = t.vmin, hb = t.hb;
-  int imax = t.imax, imin = t.imin, mb = t.mb;
+  int imax = t.imax < 0 ? -1 : t.imax + 2 * tid, imin = t.imin < 0 ? -1 : t.imin + 2 * tid, mb = t.mb < 0 ? -1 : t.mb + 2 * tid;
   block_arg<0, kNWS>(vmax, imax, s.red_d, s.red_i, tid);
   block_arg<1, kNWS>(vmin, imin, s.red_d, s.red_i, tid);
   block_arg<2, kNWS>(hb, mb, s.red_d, s.red_i, tid);

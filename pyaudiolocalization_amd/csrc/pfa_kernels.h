@@ -8,14 +8,7 @@ namespace pal {
 constexpr int kPfaTC = 11;   // output indices t per wavefront of the column pass (x 4 accumulators each)
 constexpr int kPfaUnr = 4;   // steps j per loop iteration of the column pass (the table is padded with kPfaUnr zero rows)
 
-// ------------------------------------------------------------------ stage functors of the row pass
-template <int LM> struct PfaHhatToLds {   // last stage of the forward FFT: times the chirp spectrum, into LDS
-  static constexpr bool kLds = true;
-  cd* data;
-  const cd* hh;
-  __device__ void operator()(int t, int e, cd v) const { data[lds_addr<LM, false, 2>(t, e)] = cmul(v, hh[e]); }
-};
-
+// ------------------------------------------------------------------ functors of the chirp-spectrum setup kernel
 template <int LM> struct PfaChirpIn {     // chirp kernel of the convolution: h[d mod M] = conj(b[|d|]), |d| < N2
   static constexpr bool kLds = false;
   const cd* b;
