@@ -100,6 +100,13 @@ static int check_status(Engine* e) {
   int st = 0;
   int rc = e->check(hipMemcpy(&st, e->ws[7], sizeof st, hipMemcpyDeviceToHost), "status read");
   if (rc != PAL_OK) return rc;
+  if (getenv("PAL_DEBUG_FALLBACK")) {   // diagnostics: rows whose median needed the radix select since the last report
+    int slow = 0;
+    if (hipMemcpy(&slow, static_cast<int*>(e->ws[7]) + 1, sizeof slow, hipMemcpyDeviceToHost) == hipSuccess && slow) {
+      fprintf(stderr, "[pal] %d row(s) took the radix-select fallback\n", slow);
+      hipMemset(static_cast<int*>(e->ws[7]) + 1, 0, sizeof slow);
+    }
+  }
   if (st) {
     hipMemset(e->ws[7], 0, sizeof st);
     return e->fail(PAL_ERR_INTERNAL, "peak selection: suppression chain exceeded the on-chip memo/stack (rows fell back to argmax)");
