@@ -140,3 +140,28 @@ def waveform_digest(x: np.ndarray) -> np.ndarray:
     x = np.asarray(x, dtype=np.float64)
     idx = np.linspace(0, x.shape[0] - 1, 64).astype(np.int64)
     return np.concatenate(([x.shape[0], x.sum(), (x * x).sum(), np.abs(x).max()], x[idx]))
+
+
+def calibration_cases():
+    """(tag, config, seed) for calibration.py's run_calibration: a chirp over six scattered microphones and an impulse
+    over four; `seed` goes to np.random.seed right before the call (the reference draws its noise from the global RNG)."""
+    rng = np.random.default_rng(77)
+    mics6 = [list(map(float, m)) for m in rng.uniform(-1.5, 1.5, (6, 3))]
+    mics4 = [[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.2, 0.0], [0.3, 0.4, 0.9]]
+    base = {"celsius": 20.0, "humidity": 50.0}
+    chirp = dict(base, fs=16000, duration=0.25, source_position=[2.5, -1.0, 0.8], mic_positions=mics6,
+                 calibration={"signal_type": "chirp", "freq_start": 500, "freq_end": 5000, "attenuation_factor": 1.0,
+                              "noise_level": 0.01})
+    impulse = dict(base, fs=8000, duration=0.2, source_position=[1.7, 2.2, -0.4], mic_positions=mics4,
+                   calibration={"signal_type": "impulse", "attenuation_factor": 0.8, "noise_level": 0.002})
+    return [("chirp6", chirp, 4321), ("impulse4", impulse, 99)]
+
+
+def calibration_noise(cfg, seed):
+    """The noise the reference draws for `cfg` after np.random.seed(seed): one normal(0, level, N) per microphone."""
+    n = int(cfg["fs"] * cfg["duration"])
+    state = np.random.get_state()
+    np.random.seed(seed)
+    noise = np.array([np.random.normal(0, cfg["calibration"].get("noise_level", 0.01), size=n) for _ in cfg["mic_positions"]])
+    np.random.set_state(state)
+    return noise

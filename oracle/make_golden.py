@@ -229,9 +229,24 @@ def golden_images():
     save("image_sources.npz", **out)
 
 
+def golden_calibration():
+    """calibration.py end to end (run_calibration) with the global NumPy RNG seeded in front of the noise draws."""
+    import calibration as ref_cal
+    out = {}
+    for tag, cfg, seed in cases.calibration_cases():
+        np.random.seed(seed)
+        results, calib, recs = ref_cal.run_calibration(cfg)
+        out[f"{tag}_delay"] = np.array([r["delay"] for r in results])
+        out[f"{tag}_amplitude"] = np.array([r["amplitude"] for r in results])
+        out[f"{tag}_calib_head"] = np.asarray(calib[:64])
+        out[f"{tag}_calib_digest"] = cases.waveform_digest(np.asarray(calib))
+        out[f"{tag}_rec_digest"] = np.array([cases.waveform_digest(np.asarray(r)) for r in recs])
+    save("calibration.npz", **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["edges", "filters", "images", "c1", "c2", "metric", "c4", "c5", "c3"]
-    table = {"edges": golden_selection_edges, "filters": golden_filters, "images": golden_images, "c1": golden_c1,
+    todo = sys.argv[1:] or ["edges", "filters", "images", "c1", "c2", "metric", "c4", "c5", "c3", "calibration"]
+    table = {"calibration": golden_calibration, "edges": golden_selection_edges, "filters": golden_filters, "images": golden_images, "c1": golden_c1,
              "c2": golden_c2, "c3": golden_c3, "c4": golden_c4, "c5": golden_c5, "metric": golden_metric}
     for key in todo:
         t0 = time.time()

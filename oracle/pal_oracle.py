@@ -531,3 +531,48 @@ def tdoa_stage(signals: Sequence[np.ndarray], fs: float, filter_method: str = "b
     table["L"] = filt.shape[1]
     table["filtered"] = filt
     return table
+
+
+# ---------------------------------------------------------------- calibration path
+def generate_calibration_signal(fs, duration=1.0, signal_type="chirp", freq_start=500, freq_end=5000) -> np.ndarray:
+    """calibration.py:10-21: linear chirp (or unit impulse), normalised and compressed."""
+    from scipy.signal import chirp
+    t = np.linspace(0, duration, int(fs * duration), endpoint=False)
+    if signal_type == "chirp":
+        sig = chirp(t, f0=freq_start, f1=freq_end, t1=duration, method="linear")
+    elif signal_type == "impulse":
+        sig = np.zeros_like(t)
+        sig[0] = 1.0
+    else:
+        raise ValueError("Unsupported calibration signal type. Use 'chirp' or 'impulse'.")
+    return dynamic_range_compression(normalize_signal(sig))
+
+
+def simulate_calibration_recording(calib_signal, mic_positions, source_position, fs, c, attenuation_factor=1.0,
+                                   noise_level=0.01, freq=None, material_properties=None, noise=None) -> List[np.ndarray]:
+    """calibration.py:23-41: per mic one fractional delay of the calibration signal, air attenuation, additive
+    Gaussian noise.  `noise[M][N]` replaces the reference's unseeded np.random.normal draws (same order: one
+    draw of N samples per mic) so that tests are deterministic."""
+    if freq is None:
+        freq = 1000
+    if material_properties is None:
+        raise ValueError("pass the material table (the reference defaults to materials.material_properties)")
+    out = []
+    for m, mic in enumerate(mic_positions):
+        dist = float(np.linalg.norm(np.array(source_position) - np.array(mic)))
+        rec = fractional_delay(np.asarray(calib_signal, dtype=float), dist / c, fs) * (
+            attenuation_factor * attenuation(dist, "air", freq, material_properties))
+        rec = rec + (np.random.normal(0, noise_level, size=rec.shape) if noise is None else noise[m])
+        out.append(rec)
+    return out
+
+
+def analyze_calibration(recorded_signals, calib_signal, fs) -> List[Dict[str, float]]:
+    """calibration.py:43-52: full cross-correlation against the calibration signal, lag of max |corr|."""
+    results = []
+    n_ref = len(calib_signal)
+    for rec in recorded_signals:
+        corr = xcorr_full(np.asarray(rec, dtype=float), np.asarray(calib_signal, dtype=float))
+        k = int(np.argmax(np.abs(corr)))
+        results.append({"delay": (k - (n_ref - 1)) / fs, "amplitude": float(np.max(np.abs(corr)))})
+    return results

@@ -1,6 +1,6 @@
 """MI355X-native GCC-PHAT TDOA engine behind PyAudioLocalization's function signatures.
 
-    from pyaudiolocalization_amd import main, utils, signal_processing, materials
+    from pyaudiolocalization_amd import main, utils, signal_processing, materials, calibration
 
 mirrors the reference's flat modules for the hot path named in BASELINE.json: all-pairs PHAT
 cross-correlation / peak selection, the image-source multipath simulator, the Butterworth

@@ -904,7 +904,7 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
   // segments: about 1024 workgroups per launch (four resident per CU, all in flight at once), so that a workgroup
   // streams as many tiles as possible behind one set of fixed costs (row parameters, reductions, publish)
   const int ntiles = ((n + 1) / 2 + kTile - 1) / kTile;
-  int want = (1024 + rows - 1) / rows;
+  int want = 1024 / rows;                                     // (rounded down: one resident round rather than a second, short one)
   want = want < 1 ? 1 : (want > ntiles ? ntiles : want);
   a.tiles_per_seg = (ntiles + want - 1) / want;
   if (a.tiles_per_seg > kMaxTilesPerSeg) a.tiles_per_seg = kMaxTilesPerSeg;   // the segment's bracket values must fit its LDS list

@@ -420,3 +420,20 @@ def test_rccl_single_rank_gather(engine):
     engine.free(d_a)
     engine.free(d_b)
     assert np.array_equal(back["k_sel"], np.arange(10))
+
+
+def test_calibration_dropin(golden):
+    """calibration.py drop-in on the engine: batched fractional delays + batched correlations against
+    the calibration signal reproduce the reference's run_calibration (same noise draws): lags exact, amplitudes and
+    waveforms to fp64 rounding of the exact-length transforms."""
+    from pyaudiolocalization_amd import calibration as cal_mod
+    g = golden("calibration.npz")
+    for tag, cfg, seed in cases.calibration_cases():
+        results, calib, recs = cal_mod.run_calibration(cfg, noise=cases.calibration_noise(cfg, seed))
+        digest_close([calib], g[f"{tag}_calib_digest"][None], 1e-12)
+        digest_close(recs, g[f"{tag}_rec_digest"], 1e-11)
+        assert np.array_equal(np.array([r["delay"] for r in results]), g[f"{tag}_delay"])      # integer lag / fs: exact
+        assert np.allclose([r["amplitude"] for r in results], g[f"{tag}_amplitude"], rtol=1e-10, atol=0)
+        assert all(isinstance(r["delay"], np.floating) for r in results)
+    with pytest.raises(ValueError):
+        cal_mod.generate_calibration_signal(8000, 0.1, signal_type="noise")

@@ -128,3 +128,25 @@ def test_metric_frames_first8(golden):
     idx = np.arange(0, 28, 2)
     for med in (0.05, None):
         check_table(IMPL.pair_table(frames, 44100, med, idx), g, tag_of(med), idx, exact_values=True)
+
+
+def test_calibration_path(golden):
+    """calibration.py: oracle restatement against run_calibration of the unmodified reference, with the
+    reference's own noise draws (np.random.seed in front of the call, one normal(0, level, N) per microphone)."""
+    from pyaudiolocalization_amd.materials import material_properties
+    g = golden("calibration.npz")
+    for tag, cfg, seed in cases.calibration_cases():
+        cal = cfg["calibration"]
+        c = O.speed_of_sound(cfg["celsius"], cfg["humidity"])
+        calib = O.generate_calibration_signal(cfg["fs"], cfg["duration"], signal_type=cal.get("signal_type", "chirp"),
+                                              freq_start=cal.get("freq_start", 500), freq_end=cal.get("freq_end", 5000))
+        assert np.array_equal(calib[:64], g[f"{tag}_calib_head"])
+        digest_close([calib], g[f"{tag}_calib_digest"][None], 1e-13)
+        recs = O.simulate_calibration_recording(calib, cfg["mic_positions"], cfg["source_position"], cfg["fs"], c,
+                                                attenuation_factor=cal.get("attenuation_factor", 1.0),
+                                                noise_level=cal.get("noise_level", 0.01), material_properties=material_properties,
+                                                noise=cases.calibration_noise(cfg, seed))
+        digest_close(recs, g[f"{tag}_rec_digest"], 1e-13)
+        res = O.analyze_calibration(recs, calib, cfg["fs"])
+        assert np.array_equal(np.array([r["delay"] for r in res]), g[f"{tag}_delay"])          # integer lag / fs
+        assert np.allclose([r["amplitude"] for r in res], g[f"{tag}_amplitude"], rtol=1e-12, atol=0)
