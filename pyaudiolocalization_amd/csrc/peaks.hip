@@ -100,7 +100,7 @@ struct Shared {                          // pivot and finish kernels
 };
 
 struct StreamShared {                    // stream kernel
-  double list[kLoc];
+  double list[kLoc + 1];                 // + one dump slot for the unconditional stores of values outside the bracket
   double red_d[kNWS];
   double many[kNWS * 8];
   int red_i[kNWS];
@@ -635,10 +635,14 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
         t.below += int(va && ma < lo) + int(vb && mb_ < lo);
         const bool ha = va && ma >= lo && ma <= hi, hb_ = vb && mb_ >= lo && mb_ <= hi;
         const unsigned long long m0 = __ballot(ha), m1 = __ballot(hb_);
-        off[2 * k] = ha ? run + int(__builtin_amdgcn_mbcnt_hi(unsigned(m0 >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m0), 0u))) : -1;
+        // slot inside the tile's reservation, or the dump slot kLoc for values outside the bracket: the LDS store
+        // below is unconditional (a guarded store costs a divergent branch per sample)
+        const int ra = run + int(__builtin_amdgcn_mbcnt_hi(unsigned(m0 >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m0), 0u)));
         run += __popcll(m0);
-        off[2 * k + 1] = hb_ ? run + int(__builtin_amdgcn_mbcnt_hi(unsigned(m1 >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m1), 0u))) : -1;
+        const int rb = run + int(__builtin_amdgcn_mbcnt_hi(unsigned(m1 >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m1), 0u)));
         run += __popcll(m1);
+        off[2 * k] = ha ? ra : kLoc;
+        off[2 * k + 1] = hb_ ? rb : kLoc;
       }
     }
     if (__ballot(plateau)) {                                   // equal neighbours somewhere in the tile: the exact, slow test
@@ -658,8 +662,10 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
       base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) {
-        if (off[2 * k] >= 0 && base + off[2 * k] < kLoc) s.list[base + off[2 * k]] = fabs(xa[k]);
-        if (off[2 * k + 1] >= 0 && base + off[2 * k + 1] < kLoc) s.list[base + off[2 * k + 1]] = fabs(xb[k]);
+        const int ia = off[2 * k] < kLoc ? min(base + off[2 * k], kLoc) : kLoc;
+        const int ib = off[2 * k + 1] < kLoc ? min(base + off[2 * k + 1], kLoc) : kLoc;
+        s.list[ia] = fabs(xa[k]);
+        s.list[ib] = fabs(xb[k]);
       }
     }
   };
