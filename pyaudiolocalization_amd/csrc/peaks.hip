@@ -171,6 +171,27 @@ __device__ void find_bin(Shared& s, int tid, unsigned rank, unsigned& bin, unsig
   __syncthreads();
 }
 
+// bins of s.hist that hold the 0-based ranks `ra` <= `rb` (one scan, half the barriers of two find_bin calls)
+__device__ void find_two_bins(Shared& s, int tid, unsigned ra, unsigned rb, unsigned& bin_a, unsigned& bin_b) {
+  constexpr int kPer = kBins / kT;
+  unsigned h[kPer], own = 0;
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) { h[q] = s.hist[kPer * tid + q]; own += h[q]; }
+  unsigned ex = block_excl_scan(own, s, tid);
+  if (tid == 0) { s.bc_i[0] = -1; s.bc_i[1] = -1; }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    if (ra >= ex && ra < ex + h[q]) s.bc_i[0] = kPer * tid + q;
+    if (rb >= ex && rb < ex + h[q]) s.bc_i[1] = kPer * tid + q;
+    ex += h[q];
+  }
+  __syncthreads();
+  bin_a = s.bc_i[0] < 0 ? unsigned(kBins - 1) : unsigned(s.bc_i[0]);   // rank beyond the histogram's total
+  bin_b = s.bc_i[1] < 0 ? unsigned(kBins - 1) : unsigned(s.bc_i[1]);
+  __syncthreads();
+}
+
 // wavefront-aggregated append to an LDS list (one LDS atomic per wavefront)
 __device__ __forceinline__ void append(bool pred, double v, double* list, int* counter, int cap, int lane) {
   const unsigned long long mask = __ballot(pred);
@@ -537,8 +558,10 @@ __global__ __launch_bounds__(kT) void k_peak_pivots(PeakArgs a) {
     ssum += sv[q];
     sabs += fabs(sv[q]);
   }
-  const double k0 = bsum(ssum, s, tid) / double(ns);          // ~ mean(x)
-  const double ka = bsum(sabs, s, tid) / double(ns);          // ~ mean(|x|)
+  double both[2] = {ssum, sabs};
+  bsum_many<2, kNW>(both, s.many, tid);
+  const double k0 = both[0] / double(ns);                     // ~ mean(x)
+  const double ka = both[1] / double(ns);                     // ~ mean(|x|)
   double lo = 0, hi = INFINITY;
   if (a.method == 0) {
     const unsigned r1 = unsigned((n - 1) / 2), r2 = unsigned(n / 2);   // ranks of the median's one or two order statistics
@@ -561,9 +584,8 @@ __global__ __launch_bounds__(kT) void k_peak_pivots(PeakArgs a) {
     const long long c1 = (long long)r1 * ns / n, c2 = (long long)r2 * ns / n;
     const unsigned slo = unsigned(c1 - margin > 0 ? c1 - margin : 0);
     const unsigned shi = unsigned(c2 + margin < ns - 1 ? c2 + margin : ns - 1);
-    unsigned b_lo, b_hi, t0, t1;
-    find_bin(s, tid, slo, b_lo, t0, t1);
-    find_bin(s, tid, shi, b_hi, t0, t1);
+    unsigned b_lo, b_hi;
+    find_two_bins(s, tid, slo, shi, b_lo, b_hi);
     lo = double(b_lo) / inv;
     hi = b_hi >= unsigned(kBins - 1) ? INFINITY : double(b_hi + 1) / inv;
     if (slo == 0) lo = 0;
@@ -778,8 +800,10 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
     w1 += d;
     w2 += d * d;
   }
-  w1 = bsum(w1, s, tid);
-  w2 = bsum(w2, s, tid);
+  double wsum[2] = {w1, w2};
+  bsum_many<2, kNW>(wsum, s.many, tid);
+  w1 = wsum[0];
+  w2 = wsum[1];
   const double nn = double(n - (whi_s - wlo_s));
   double o1 = s1 - w1, o2 = s2 - w2;
   if (!(o2 >= 0.25 * s2)) {
