@@ -437,3 +437,22 @@ def test_calibration_dropin(golden):
         assert all(isinstance(r["delay"], np.floating) for r in results)
     with pytest.raises(ValueError):
         cal_mod.generate_calibration_signal(8000, 0.1, signal_type="noise")
+
+
+def test_small_and_odd_lengths_both_routes(engine):
+    """Every frame length 1..24 and a spread of odd / power-of-two neighbours: n = 2L-1 walks through one-tile
+    prime-factor plans (n < 1024, n prime or not), multi-row plans (2045 = 5 x 409, 2049 = 3 x 683) and lengths that
+    stay on the four-step route (n = 1, 2047); unequal lengths make n even (four-step)."""
+    rng = np.random.default_rng(3)
+    for length in list(range(1, 25)) + [45, 64, 100, 255, 256, 257, 496, 512, 1023, 1024, 1025]:
+        a, b = rng.standard_normal(length), rng.standard_normal(length)
+        assert np.max(np.abs(engine.phat_correlation(a, b) - O.phat_correlation(a, b))) < 1e-13, length
+    for n1, n2 in ((3, 7), (10, 4), (33, 32), (100, 41), (500, 496)):
+        a, b = rng.standard_normal(n1), rng.standard_normal(n2)
+        assert np.max(np.abs(engine.phat_correlation(a, b) - O.phat_correlation(a, b))) < 1e-13, (n1, n2)
+    for length in (8, 16, 33):
+        frames = rng.standard_normal((2, 4, length))
+        table = engine.gcc_phat_all_pairs(frames, 8000.0)
+        for t in range(2):
+            want = O.all_pairs(frames[t], 8000.0)
+            assert np.array_equal(table[t]["k_sel"], want["k_sel"]) and np.array_equal(table[t]["branch"], want["branch"])
