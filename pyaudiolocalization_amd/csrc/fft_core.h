@@ -231,6 +231,25 @@ PAL_HD void stage_load(const In& in, const cd* tw, int w, cd* v) {
   dftR<R, INV>(v);
 }
 
+// the same with the stage's twiddle factors handed over in registers: f[r] = exp(-2 pi i k r / (P R)), 1 <= r < R
+template <int LOG2N, bool COLS, bool INV, int LOG2P, int NSUB, class In>
+PAL_HD void stage_load_with(const In& in, int w, cd* v, const cd* f) {
+  constexpr int R = stage_radix(LOG2N, LOG2P), N = 1 << LOG2N, NB = N / R;
+  int i, t;
+  item_of<LOG2N, COLS, R, NSUB>(w, i, t);
+  if constexpr (has_direct<In>::value) {
+    const int b = in.base(t, i);
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = in.at(b, r * NB);
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = in(t, i + r * NB);
+  }
+#pragma unroll
+  for (int r = 1; r < R; ++r) v[r] = INV ? cmulc(v[r], f[r]) : cmul(v[r], f[r]);
+  dftR<R, INV>(v);
+}
+
 // hand the R outputs of work item w to `out(t, e, value)` at their autosort positions
 template <int LOG2N, bool COLS, int LOG2P, int NSUB, class Out>
 PAL_HD void stage_store(const Out& out, int w, const cd* v) {

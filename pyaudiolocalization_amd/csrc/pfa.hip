@@ -88,7 +88,7 @@ int Engine::build_pfa(Plan& pl) {
   const int h = (bn1 - 1) / 2;
   f.nch = h > 0 ? (h + kPfaTC - 1) / kPfaTC : 1;
   const cd* tws = blm >= 11 ? stage_table_compact(blm) : stage_table(blm);
-  if (!tws) return fail(PAL_ERR_NOMEM, "twiddle tables");
+  if (!tws || !stage_table(blm)) return fail(PAL_ERR_NOMEM, "twiddle tables");   // (the full table feeds the register twiddles)
   PAL_HIP(hipMalloc(&f.b, sizeof(cd) * bn2));
   PAL_HIP(hipMalloc(&f.hhat, sizeof(cd) << blm));
   PAL_HIP(hipMalloc(&f.r1, sizeof(cd) * bn1));
@@ -136,7 +136,7 @@ int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads
     char name[48];
     snprintf(name, sizeof name, "k_pfa_rows<%d>", f.lm);
     ProfScope ps(this, name, on);
-    PfaRowsArgs a{permuted, quads, Y, f.b, f.hhat, f.r1, tws, f.rowtab, f.n1, f.n2, f.rows(), G, f.u1, 1.0f / float(f.n1), nullptr};
+    PfaRowsArgs a{permuted, quads, Y, f.b, f.hhat, f.r1, tws, stage_table(f.lm), f.rowtab, f.n1, f.n2, f.rows(), G, f.u1, 1.0f / float(f.n1), nullptr};
     const unsigned grid = unsigned(G) * unsigned(f.rows());
     PAL_SWITCH_LM(f.lm, k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, on>>>(a));
     PAL_HIP(hipGetLastError());

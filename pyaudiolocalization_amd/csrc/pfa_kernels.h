@@ -31,7 +31,11 @@ template <int LM> struct PfaScaledOut {
 template <int LM> struct PfaLds {         // LDS sizes of the row pass
   static constexpr bool kCompact = LM >= 11;
   static constexpr int kM = 1 << LM, kLanes = 2 * kM / 16;
-  static constexpr int kTw = kCompact ? stage_twc_size(LM) : stage_tw_size(LM);
+  // up to 2048-point tiles the last stage's twiddles live in registers (read once from the full table in global
+  // memory, used by the seam and by the last inverse stage): the LDS table then ends before that stage
+  static constexpr bool kRegTw = LM <= 11;
+  static constexpr int kTwAll = kCompact ? stage_twc_size(LM) : stage_tw_size(LM);     // every stage (setup kernel)
+  static constexpr int kTw = kRegTw ? stage_tw_offset(LM, stage_tw_last(LM)) : kTwAll;   // row pass
   static constexpr int kTwPad = (kTw + kLanes - 1) / kLanes * kLanes;   // whole rounds of the workgroup: an unguarded copy
 };
 
@@ -40,9 +44,9 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_hhat(const cd* __res
                                                                  double scale, const cd* __restrict__ tws) {
   using L = PfaLds<LM>;
   __shared__ cd data[2 * L::kM];
-  __shared__ cd tw[L::kTw];
+  __shared__ cd tw[L::kTwAll];
   const int tid = threadIdx.x;
-  for (int i = tid; i < L::kTw; i += L::kLanes) tw[i] = tws[i];
+  for (int i = tid; i < L::kTwAll; i += L::kLanes) tw[i] = tws[i];
   wg_fft<LM, false, false, 2, L::kCompact>(data, tw, tid, PfaChirpIn<LM>{b, N2}, PfaScaledOut<LM>{hhat, scale});
 }
 
@@ -51,6 +55,7 @@ struct PfaRowsArgs {
   const int4* quad;    // mic rows (a, b) of pair p and (c, d) of pair q; c < 0: no second pair
   cd* Y;               // [G][N1][N2]
   const cd *b, *hhat, *r1, *tws;
+  const cd* twfull;    // full (non-compact) stage table of the tile length: source of the register twiddles
   const int2* rowtab;  // per row of Y: (u1 row mod N1, u1 row P mod N1) with P = points per last-stage butterfly group
   int N1, N2, NR, G, u1;
   float inv;
@@ -161,10 +166,20 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
   // the sixteen chirp-spectrum values of this lane's seam butterfly: requested now, used after the middle stages
   // (the registers are free: LDS, not the register file, limits this kernel to two wavefronts per SIMD)
   cd hh[16];
+  constexpr int kFt = L::kRegTw ? 16 / stage_radix(LM, stage_tw_last(LM)) : 1, kFr = L::kRegTw ? stage_radix(LM, stage_tw_last(LM)) : 1;
+  cd ftw[kFt][kFr];                                           // last-stage twiddles of this lane's butterflies k = i + NB q
   {
     const int i = tid % NB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hh[r] = a.hhat[i + NB * r];
+    if constexpr (L::kRegTw) {
+      constexpr int lpl = stage_tw_last(LM), pl = 1 << lpl;
+      const cd* src = a.twfull + stage_tw_offset(LM, lpl);
+#pragma unroll
+      for (int q = 0; q < kFt; ++q)
+#pragma unroll
+        for (int r = 1; r < kFr; ++r) ftw[q][r] = src[(r - 1) * pl + i + NB * q];
+    }
     asm volatile("" ::: "memory");                            // keep the loads here (the scheduler would sink them to their use)
   }
 
@@ -173,18 +188,20 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
   stamp();
 
   // ---- 3. last forward stage x chirp spectrum x first inverse stage
+  constexpr int LPL = stage_tw_last(LM), RL = stage_radix(LM, LPL), P = 1 << LPL, SPLIT = 16 / RL, HR = RL / 2;
+  static_assert(RL == 8 || RL == 16, "last-stage radix");
+  // This lane's butterflies of the last stage, in the seam AND in the last inverse stage: tile ts, k = is + NB q.
+  const int ts = tid / NB, is = tid % NB;
   {
-    constexpr int LPL = stage_tw_last(LM), RL = stage_radix(LM, LPL), P = 1 << LPL, SPLIT = 16 / RL;
-    static_assert(RL == 8 || RL == 16, "last-stage radix");
-    const int t = tid / NB, i = tid % NB;
     cd u[16];
 #pragma unroll
     for (int q = 0; q < SPLIT; ++q) {
       cd v[RL];
-      const int k = i + NB * q;                               // < P: butterfly of the last stage, outputs k + P r
-      stage_load<LM, false, false, LPL, 2, CT>(tile, tw, t * P + k, v);
+      const int k = is + NB * q;                              // < P: outputs k + P r
+      if constexpr (L::kRegTw) stage_load_with<LM, false, false, LPL, 2>(tile, ts * P + k, v, ftw[q]);
+      else stage_load<LM, false, false, LPL, 2, CT>(tile, tw, ts * P + k, v);
 #pragma unroll
-      for (int r = 0; r < RL; ++r) u[q + SPLIT * r] = cmul(v[r], hh[q + SPLIT * r]);   // element k + P r = i + NB (q + SPLIT r)
+      for (int r = 0; r < RL; ++r) u[q + SPLIT * r] = cmul(v[r], hh[q + SPLIT * r]);   // element k + P r = is + NB (q + SPLIT r)
     }
     __syncthreads();                                          // every lane has read its inputs
     dft16<true>(u);
@@ -198,22 +215,20 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
   //         (tile 0: row k1, m2 = e; tile 1: row N1 - k1 of the reversed transform, m2 = -e mod N2).  The twiddle
   //         index u1 row m2 mod N1 advances by a wave-uniform step from one output of a butterfly to the next.
   {
-    constexpr int LPL = stage_tw_last(LM), RL = stage_radix(LM, LPL), P = 1 << LPL, PER = 16 / RL, HR = RL / 2;
     cd* const Yg = a.Y + size_t(g) * a.N1 * a.N2;
     const int N1 = a.N1, N2 = a.N2;
-    const int kr = k1 ? N1 - k1 : 0;
+    const int t = __builtin_amdgcn_readfirstlane(ts);         // tile: wave-uniform (NB lanes = whole wavefronts)
+    const int row = t ? (k1 ? N1 - k1 : 0) : k1;
     // chirp and column-twiddle factors of this lane's outputs: requested before the inverse middle stages, which touch
     // only LDS, so that they have landed when the last stage needs them
-    cd fb[PER][HR], fr[PER][HR];
-    int m2s[PER][HR];
+    cd fb[SPLIT][HR], fr[SPLIT][HR];
+    int m2s[SPLIT][HR];
+    // scalar load (constant address space): u1 row mod N1 and the index step between outputs
+    const auto* rt = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.rowtab)) + 2 * row;
+    const unsigned uk = unsigned(rt[0]), step = unsigned(rt[1]), n1 = unsigned(N1);
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const int w = tid + L::kLanes * q;
-      const int t = __builtin_amdgcn_readfirstlane(w / P), k = w % P;   // tile (wave-uniform), butterfly
-      const int row = t ? kr : k1;
-      // scalar load (constant address space): u1 row mod N1 and the index step between outputs
-      const auto* rt = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.rowtab)) + 2 * row;
-      const unsigned uk = unsigned(rt[0]), step = unsigned(rt[1]), n1 = unsigned(N1);
+    for (int q = 0; q < SPLIT; ++q) {
+      const int k = is + NB * q;
       const int mb = t ? N2 - k : k;                                    // m2 of output r is mb -/+ P r (tile 1: except e = 0)
       const unsigned x = __umul24(uk, unsigned(mb));                    // < 2^24: exact in float
       unsigned idx = x - __umul24(unsigned(float(x) * a.inv), n1);      // x mod N1, off by at most one N1 either way
@@ -235,19 +250,20 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
     }
     asm volatile("" ::: "memory");                                      // keep these loads above the LDS-only stages
     wg_fft_middle<LM, false, true, 4, 2, CT>(data, tw, tid);
+    if (!(t == 1 && k1 == 0)) {                                         // row 0 pairs with itself: tile 1 is a duplicate
+      cd* const Yrow = Yg + size_t(row) * N2;
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const int w = tid + L::kLanes * q;
-      const int t = __builtin_amdgcn_readfirstlane(w / P), k = w % P;
-      cd v[RL];
-      stage_load<LM, false, true, LPL, 2, CT>(tile, tw, w, v);
-      if (t == 1 && k1 == 0) continue;                                  // row 0 pairs with itself: tile 1 is a duplicate
-      cd* const Yrow = Yg + size_t(t ? kr : k1) * N2;
+      for (int q = 0; q < SPLIT; ++q) {
+        const int k = is + NB * q;
+        cd v[RL];
+        if constexpr (L::kRegTw) stage_load_with<LM, false, true, LPL, 2>(tile, ts * P + k, v, ftw[q]);
+        else stage_load<LM, false, true, LPL, 2, CT>(tile, tw, ts * P + k, v);
 #pragma unroll
-      for (int r = 0; r < HR; ++r) {
-        const int e = k + P * r;
-        const cd z = cmulc(cmul(v[r], fb[q][r]), fr[q][r]);
-        if (e < N2) Yrow[m2s[q][r]] = z;
+        for (int r = 0; r < HR; ++r) {
+          const int e = k + P * r;
+          const cd z = cmulc(cmul(v[r], fb[q][r]), fr[q][r]);
+          if (e < N2) Yrow[m2s[q][r]] = z;
+        }
       }
     }
   }

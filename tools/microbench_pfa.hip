@@ -341,7 +341,7 @@ int main(int argc, char** argv) {
     for (int r = 0; r < N1; ++r) rt[r] = make_int2((68 * r) % N1, (68 * r % N1) * 256 % N1);
     CHECK(hipMemcpy(rowtab, rt.data(), sizeof(int2) * N1, hipMemcpyHostToDevice));
   }
-  PfaRowsArgs a{SP, quad, Y, b, hhat, r1, tws, rowtab, N1, N2, NR, G, 68, 1.0f / float(N1), nullptr};
+  PfaRowsArgs a{SP, quad, Y, b, hhat, r1, tws, tws, rowtab, N1, N2, NR, G, 68, 1.0f / float(N1), nullptr};
   const unsigned grid = unsigned(G) * NR, nblk = (N2 + 63) / 64;
   printf("G = %d transforms (%d pairs)\n", G, 2 * G);
   time_it("rows: product", 20, [&] { k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes)>>>(a); });
