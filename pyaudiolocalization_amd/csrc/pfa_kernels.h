@@ -63,17 +63,13 @@ struct PfaRowsArgs {
 };
 
 // v_permlane32_swap(x, y): x' = {x[0:31], y[0:31]}, y' = {x[32:63], y[32:63]} (lane ranges of the two results).
-// first_of(a, b):  lanes 0-31 keep a, lanes 32-63 receive b of their partner lane (lane - 32)
-// second_of(a, b): lanes 0-31 receive a of their partner lane (lane + 32), lanes 32-63 keep b
-__device__ __forceinline__ double first_of(double a, double b) {
-  const auto lo = __builtin_amdgcn_permlane32_swap(unsigned(__double2loint(a)), unsigned(__double2loint(b)), false, false);
-  const auto hi = __builtin_amdgcn_permlane32_swap(unsigned(__double2hiint(a)), unsigned(__double2hiint(b)), false, false);
-  return __hiloint2double(int(hi[0]), int(lo[0]));
-}
-__device__ __forceinline__ double second_of(double a, double b) {
-  const auto lo = __builtin_amdgcn_permlane32_swap(unsigned(__double2loint(a)), unsigned(__double2loint(b)), false, false);
-  const auto hi = __builtin_amdgcn_permlane32_swap(unsigned(__double2hiint(a)), unsigned(__double2hiint(b)), false, false);
-  return __hiloint2double(int(hi[1]), int(lo[1]));
+// swap_pair(a, b, lo, hi):  lo = lanes 0-31 keep a, lanes 32-63 receive b of their partner lane (lane - 32);
+//                           hi = lanes 0-31 receive a of their partner lane (lane + 32), lanes 32-63 keep b
+__device__ __forceinline__ void swap_pair(double a, double b, double& lo, double& hi) {
+  const auto l = __builtin_amdgcn_permlane32_swap(unsigned(__double2loint(a)), unsigned(__double2loint(b)), false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap(unsigned(__double2hiint(a)), unsigned(__double2hiint(b)), false, false);
+  lo = __hiloint2double(int(h[0]), int(l[0]));
+  hi = __hiloint2double(int(h[1]), int(l[1]));
 }
 
 // grid = G * NR workgroups, transform fastest so that neighbours share the tables.
@@ -139,11 +135,10 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
     }
 #pragma unroll
     for (int q = 0; q < kTwPer; ++q) tw_lds[tid + q * L::kLanes] = twr[q];
-    // Lower lanes (tile 0) whiten inputs r = 0..3 of butterfly i, upper lanes (tile 1) r = 4..7.  Each lane forms its
-    // own tile's value `own` and the other tile's value `oth` of the same bin: with sg = +1 / -1 for tile 0 / 1
-    //   tile 0: R^p + i R^q,  tile 1: conj(R^p) + i conj(R^q)   =>   own = (r1.x - sg r2.y, sg r1.y + r2.x), oth = own(-sg)
-    // and two half-wave swaps per register put r = 0..3 / 4..7 of BOTH tiles where their butterflies expect them.
-    const double sg = upper ? -1.0 : 1.0;
+    // Lower lanes (tile 0) whiten inputs r = 0..3 of butterfly i, upper lanes (tile 1) r = 4..7.  Every lane forms both
+    // tiles' values of its bin,  x = R^p + i R^q (tile 0)  and  z = conj(R^p) + i conj(R^q) (tile 1),  and ONE half-wave
+    // swap per register sorts them: r = u of both tiles is {x of the lower lanes, z of the lower lanes moved up}, r = 4 + u
+    // is {x of the upper lanes moved down, z of the upper lanes}.
     cd v[16];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -151,10 +146,9 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
       const cd r1 = whiten(va[u], vb[u]);
       const cd r2 = cscale(whiten(vc[u], vd[u]), keep2);
       const cd c0 = e < a.N2 ? ch[u] : mk(0, 0);             // zero padding beyond N2
-      const cd own = cmul(mk(__builtin_fma(-sg, r2.y, r1.x), __builtin_fma(sg, r1.y, r2.x)), c0);
-      const cd oth = cmul(mk(__builtin_fma(sg, r2.y, r1.x), __builtin_fma(-sg, r1.y, r2.x)), c0);
-      v[u] = mk(first_of(own.x, oth.x), first_of(own.y, oth.y));          // r = u:     tile 0 own, tile 1 from its partner
-      v[4 + u] = mk(second_of(oth.x, own.x), second_of(oth.y, own.y));    // r = 4 + u: tile 0 from its partner, tile 1 own
+      const cd x = cmul(mk(r1.x - r2.y, r1.y + r2.x), c0), z = cmul(mk(r1.x + r2.y, r2.x - r1.y), c0);
+      swap_pair(x.x, z.x, v[u].x, v[4 + u].x);
+      swap_pair(x.y, z.y, v[u].y, v[4 + u].y);
       v[8 + u] = v[12 + u] = mk(0, 0);
     }
     dft16<false>(v);
