@@ -42,6 +42,10 @@ struct Pfa {
   cd* r1 = nullptr;        // exp(-2 pi i q / N1), q < N1
   double* T = nullptr;     // cos / sin (2 pi j t / N1) in the column pass's chunked order
   int2* rowtab = nullptr;  // per row of Y: (u1 row mod N1, its step between outputs of a last-stage butterfly)
+  // Rader variant of the row pass (pfa_rader.h) when N2 is prime and N2 - 1 = 11 x 9 x 10
+  bool rader = false;
+  cd *rd_bhat = nullptr, *rd_tw2f = nullptr, *rd_tw2i = nullptr, *rd_tw3f = nullptr, *rd_tw3i = nullptr;
+  int *rd_qidx = nullptr, *rd_ridx = nullptr;
   int rows() const { return (n1 + 1) / 2; }   // spectrum rows k1 <= (N1-1)/2 kept by the permuted layout
   bool on() const { return n1 > 0; }
 };
@@ -78,6 +82,7 @@ struct Engine {
                                    // 2 transforms on `stream`, peak selection on `stream2`; 3 groups rotate over three streams
   bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
   bool allow_pfa = true;           // PAL_PFA=0 keeps the PHAT inverse on the four-step chirp convolution
+  bool allow_rader = true;         // PAL_RADER=0 keeps the row pass on the in-LDS chirp convolution
   int pfa_sub = 0;                 // transforms per row/column pass of the prime-factor route (PAL_PFA_SUB; 0 = whole group)
   std::string err;
   int chunk = 128;                              // transforms per launch group (256 PHAT rows per peak-kernel launch: one per CU)
@@ -111,6 +116,7 @@ struct Engine {
   const cd* stage_table_compact(int ln);
   int build_pfa(Plan& pl);                  // pfa.hip: choose the split and make the tables (leaves pl.pfa off if none fits)
   void free_pfa(Pfa& f);
+  int build_rader(Pfa& f, long long n, long long u2);   // pfa.hip: Rader tables when N2 is 991
   int pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, double* corr, size_t stride,
                      hipStream_t on);
   int get_plan(int n, int lin, int nout, Plan** out);

@@ -1,0 +1,135 @@
+// mixed_radix.h - radix 9 / 10 / 11 butterflies and the mixed-radix Stockham stages of the Rader row pass (gfx950,
+// fp64).  Rader's algorithm turns the N2-point DFT of a prime N2 into a cyclic convolution of length N2 - 1; for
+// N2 = 991 that is 990 = 11 x 9 x 10 points instead of the 2048-point chirp convolution (pfa_rader.h).
+//
+// The butterflies use the real-symmetric form of a length-R DFT: with a_k = x_k + x_{R-k}, b_k = x_k - x_{R-k},
+//   X_m, X_{R-m} = x_0 + sum_k cos(2 pi k m / R) a_k  -/+  i sum_k sin(2 pi k m / R) b_k        (forward)
+// i.e. ((R-1)/2)^2 real-by-complex multiply-adds for the cosine part and as many for the sine part.  The tables
+// below were generated with 40-digit arithmetic (tools: mpmath) and are exact to the last bit of a double.
+//
+// The index math is __host__ __device__ so that tests/host/test_fft_core.cpp runs the same stage code on the CPU.
+#pragma once
+#include "fft_core.h"
+
+namespace pal {
+
+template <int R> struct Roots;   // cos / sin of 2 pi q / R
+template <> struct Roots<9> {
+  static PAL_HD constexpr double c(int q) {
+    constexpr double t[9] = {1.0, 7.660444431189780352e-1, 1.7364817766693034885e-1, -5.0e-1, -9.3969262078590838405e-1, -9.3969262078590838405e-1, -5.0e-1, 1.7364817766693034885e-1, 7.660444431189780352e-1};
+    return t[q];
+  }
+  static PAL_HD constexpr double s(int q) {
+    constexpr double t[9] = {0.0, 6.4278760968653932632e-1, 9.8480775301220805937e-1, 8.6602540378443864676e-1, 3.4202014332566873304e-1, -3.4202014332566873304e-1, -8.6602540378443864676e-1, -9.8480775301220805937e-1, -6.4278760968653932632e-1};
+    return t[q];
+  }
+};
+template <> struct Roots<10> {
+  static PAL_HD constexpr double c(int q) {
+    constexpr double t[10] = {1.0, 8.090169943749474241e-1, 3.090169943749474241e-1, -3.090169943749474241e-1, -8.090169943749474241e-1, -1.0, -8.090169943749474241e-1, -3.090169943749474241e-1, 3.090169943749474241e-1, 8.090169943749474241e-1};
+    return t[q];
+  }
+  static PAL_HD constexpr double s(int q) {
+    constexpr double t[10] = {0.0, 5.8778525229247312917e-1, 9.5105651629515357212e-1, 9.5105651629515357212e-1, 5.8778525229247312917e-1, 4.1340642196527976473e-43, -5.8778525229247312917e-1, -9.5105651629515357212e-1, -9.5105651629515357212e-1, -5.8778525229247312917e-1};
+    return t[q];
+  }
+};
+template <> struct Roots<11> {
+  static PAL_HD constexpr double c(int q) {
+    constexpr double t[11] = {1.0, 8.4125353283118116886e-1, 4.1541501300188642553e-1, -1.4231483827328514044e-1, -6.5486073394528506406e-1, -9.5949297361449738989e-1, -9.5949297361449738989e-1, -6.5486073394528506406e-1, -1.4231483827328514044e-1, 4.1541501300188642553e-1, 8.4125353283118116886e-1};
+    return t[q];
+  }
+  static PAL_HD constexpr double s(int q) {
+    constexpr double t[11] = {0.0, 5.4064081745559758211e-1, 9.0963199535451837141e-1, 9.8982144188093273238e-1, 7.5574957435425828377e-1, 2.8173255684142969771e-1, -2.8173255684142969771e-1, -7.5574957435425828377e-1, -9.8982144188093273238e-1, -9.0963199535451837141e-1, -5.4064081745559758211e-1};
+    return t[q];
+  }
+};
+
+// length-R DFT in registers, R = 9, 10 or 11 (any R with a Roots<R> table), natural order in and out
+template <int R, bool INV> PAL_HD void dft_sym(cd* v) {
+  constexpr int H = (R - 1) / 2;
+  constexpr bool EVEN = (R % 2) == 0;
+  cd a[H + 1], b[H + 1];
+#pragma unroll
+  for (int k = 1; k <= H; ++k) {
+    a[k] = v[k] + v[R - k];
+    b[k] = v[k] - v[R - k];
+  }
+  const cd x0 = v[0];
+  const cd xm = EVEN ? v[R / 2] : mk(0, 0);           // the self-paired input of an even length
+  cd out[R];
+  cd sum = x0;
+#pragma unroll
+  for (int k = 1; k <= H; ++k) sum = sum + a[k];
+  out[0] = EVEN ? sum + xm : sum;
+#pragma unroll
+  for (int m = 1; m <= H; ++m) {
+    cd cr = EVEN ? ((m & 1) ? x0 - xm : x0 + xm) : x0;
+    cd si = mk(0, 0);
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
+      const int q = (k * m) % R;
+      const double c = Roots<R>::c(q), s = Roots<R>::s(q);
+      cr = mk(__builtin_fma(c, a[k].x, cr.x), __builtin_fma(c, a[k].y, cr.y));
+      si = mk(__builtin_fma(s, b[k].x, si.x), __builtin_fma(s, b[k].y, si.y));
+    }
+    // forward: e^{-i t} = cos t - i sin t, so X_m = cr - i si and X_{R-m} = cr + i si; the inverse swaps them
+    const cd lo = mk(cr.x + si.y, cr.y - si.x), hi = mk(cr.x - si.y, cr.y + si.x);
+    out[m] = INV ? hi : lo;
+    out[R - m] = INV ? lo : hi;
+  }
+  if (EVEN) {                                         // X_{R/2} = sum_k (-1)^k x_k
+    cd alt = ((R / 2) & 1) ? x0 - xm : x0 + xm;
+#pragma unroll
+    for (int k = 1; k <= H; ++k) alt = (k & 1) ? alt - a[k] : alt + a[k];
+    out[R / 2] = alt;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = out[r];
+}
+
+// plain (unswizzled) tile of `pitch` elements per sub-transform: the odd strides of these stages spread over the banks
+struct PlainTile {
+  static constexpr bool kLds = true;
+  cd* data;
+  int pitch;
+  PAL_HD cd operator()(int t, int e) const { return data[t * pitch + e]; }
+  PAL_HD void operator()(int t, int e, cd v) const { data[t * pitch + e] = v; }
+};
+
+// Stockham autosort stage of an N-point transform: radix R, P = product of the radices of the earlier stages.
+// Butterfly i < N / R of sub-transform t reads elements i + r N/R, applies exp(-/+ 2 pi i k r / (P R)) with k = i mod P
+// (`tws[(r-1) P + k]`, forward values; or `f[r]` handed over in registers) and the length-R DFT; its outputs belong at
+// (i - k) R + k + r P.
+template <int N, int R, int P, bool INV, class In> PAL_HD void mr_load(const In& in, const cd* tws, int t, int i, cd* v) {
+  constexpr int NB = N / R;
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = in(t, i + r * NB);
+  if (P > 1) {
+    const int k = i % P;
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+      const cd f = tws[(r - 1) * P + k];
+      v[r] = INV ? cmulc(v[r], f) : cmul(v[r], f);
+    }
+  }
+  dft_sym<R, INV>(v);
+}
+
+template <int N, int R, bool INV, class In> PAL_HD void mr_load_with(const In& in, int t, int i, cd* v, const cd* f) {
+  constexpr int NB = N / R;
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = in(t, i + r * NB);
+#pragma unroll
+  for (int r = 1; r < R; ++r) v[r] = INV ? cmulc(v[r], f[r]) : cmul(v[r], f[r]);
+  dft_sym<R, INV>(v);
+}
+
+template <int N, int R, int P, class Out> PAL_HD void mr_store(const Out& out, int t, int i, const cd* v) {
+  const int k = i % P;
+  const int j0 = (i - k) * R + k;
+#pragma unroll
+  for (int r = 0; r < R; ++r) out(t, j0 + r * P, v[r]);
+}
+
+}  // namespace pal

@@ -242,6 +242,8 @@ int pal_create(int device, pal_handle* out) {
   if (env) e->allow_r3 = atoi(env) != 0;
   env = getenv("PAL_PFA");
   if (env) e->allow_pfa = atoi(env) != 0;
+  env = getenv("PAL_RADER");
+  if (env) e->allow_rader = atoi(env) != 0;
   env = getenv("PAL_PFA_SUB");
   if (env) e->pfa_sub = atoi(env);
   *out = reinterpret_cast<pal_handle>(e);

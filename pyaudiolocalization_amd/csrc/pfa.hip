@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "pfa_kernels.h"
+#include "pfa_rader.h"
 
 namespace pal {
 
@@ -49,6 +50,9 @@ void Engine::free_pfa(Pfa& f) {
   if (f.r1) (void)hipFree(f.r1);
   if (f.T) (void)hipFree(f.T);
   if (f.rowtab) (void)hipFree(f.rowtab);
+  for (void* p : {(void*)f.rd_bhat, (void*)f.rd_tw2f, (void*)f.rd_tw2i, (void*)f.rd_tw3f, (void*)f.rd_tw3i, (void*)f.rd_qidx,
+                  (void*)f.rd_ridx})
+    if (p) (void)hipFree(p);
   f = Pfa();
 }
 
@@ -124,7 +128,89 @@ int Engine::build_pfa(Plan& pl) {
   PAL_HIP(hipMalloc(&f.T, tab.size() * sizeof(double)));
   PAL_HIP(hipMemcpyAsync(f.T, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, stream));
   PAL_HIP(hipStreamSynchronize(stream));       // `tab` is host memory
+  if (allow_rader && bn2 == 991) PAL_TRY(build_rader(f, n, u2 % bn2));   // 991 is prime and 990 = 11 x 9 x 10
   pl.pfa = f;
+  return PAL_OK;
+}
+
+// exp(-2 pi i k r / (P R)) at [(r-1) P + k]: twiddles of a mixed-radix stage (mixed_radix.h), long-double accurate
+static void mixed_radix_twiddles(int R, int P, std::vector<cd>& tw) {
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  tw.assign(size_t(R - 1) * P, mk(0, 0));
+  for (int r = 1; r < R; ++r)
+    for (int k = 0; k < P; ++k) {
+      const long double ang = -two_pi * (long double)((long long)k * r % ((long long)P * R)) / (long double)((long long)P * R);
+      tw[size_t(r - 1) * P + k] = mk(double(cosl(ang)), double(sinl(ang)));
+    }
+}
+
+template <class T> static int upload_table(Engine* e, const std::vector<T>& host, T** dev) {
+  if (hipMalloc(dev, host.size() * sizeof(T)) != hipSuccess) return e->fail(PAL_ERR_NOMEM, "rader tables");
+  return e->check(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice), "rader tables");
+}
+
+// Rader tables of the prime N2 = f.n2 (pfa_rader.h): generator re-indexing, the spectrum of w^(g^s) with
+// w = exp(2 pi i u2 / N2), and the twiddles of the 11 x 9 x 10 (forward) / 10 x 9 x 11 (inverse) stage orders
+int Engine::build_rader(Pfa& f, long long n, long long u2) {
+  constexpr int R1 = 11, R2 = 9, R3 = 10;
+  const int p = f.n2, L = p - 1;
+  if (L != R1 * R2 * R3) return PAL_OK;
+  int g = 0;                                                   // smallest primitive root: order L, checked on L's prime factors
+  for (int c = 2; c < p && !g; ++c) {
+    bool ok = true;
+    for (int q : {2, 3, 5, 11}) {
+      long long x = 1, b = c;
+      for (int ex = L / q; ex; ex >>= 1, b = b * b % p)
+        if (ex & 1) x = x * b % p;
+      ok = ok && x != 1;
+    }
+    if (ok) g = c;
+  }
+  if (!g) return PAL_OK;
+  std::vector<int> gpow(L), qidx(p, 0), ridx(p, 0);
+  long long x = 1;
+  for (int s = 0; s < L; ++s, x = x * g % p) gpow[s] = int(x);
+  for (int s = 0; s < L; ++s) {
+    ridx[gpow[s]] = s;                                         // X[g^s] = x[0] + C[s]
+    qidx[gpow[(L - s) % L]] = s;                               // a[s] = x[g^-s]
+  }
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  std::vector<long double> br(L), bi(L);
+  for (int s = 0; s < L; ++s) {
+    const long double ang = two_pi * (long double)(u2 * gpow[s] % p) / (long double)p;
+    br[s] = cosl(ang);
+    bi[s] = sinl(ang);
+  }
+  std::vector<long double> cr(L), ci(L);
+  for (int s = 0; s < L; ++s) {
+    const long double ang = -two_pi * (long double)s / (long double)L;
+    cr[s] = cosl(ang);
+    ci[s] = sinl(ang);
+  }
+  std::vector<cd> bhat(L);
+  const long double scale = 1.0L / ((long double)L * (long double)n);
+  for (int s = 0; s < L; ++s) {
+    long double ar = 0, ai = 0;
+    for (int k = 0; k < L; ++k) {
+      const int m = int((long long)s * k % L);
+      ar += br[k] * cr[m] - bi[k] * ci[m];
+      ai += br[k] * ci[m] + bi[k] * cr[m];
+    }
+    bhat[s] = mk(double(ar * scale), double(ai * scale));
+  }
+  std::vector<cd> t2f, t2i, t3f, t3i;
+  mixed_radix_twiddles(R2, R1, t2f);
+  mixed_radix_twiddles(R2, R3, t2i);
+  mixed_radix_twiddles(R3, R1 * R2, t3f);
+  mixed_radix_twiddles(R1, R3 * R2, t3i);
+  PAL_TRY(upload_table(this, bhat, &f.rd_bhat));
+  PAL_TRY(upload_table(this, t2f, &f.rd_tw2f));
+  PAL_TRY(upload_table(this, t2i, &f.rd_tw2i));
+  PAL_TRY(upload_table(this, t3f, &f.rd_tw3f));
+  PAL_TRY(upload_table(this, t3i, &f.rd_tw3i));
+  PAL_TRY(upload_table(this, qidx, &f.rd_qidx));
+  PAL_TRY(upload_table(this, ridx, &f.rd_ridx));
+  f.rader = true;
   return PAL_OK;
 }
 
@@ -132,7 +218,13 @@ int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads
                            hipStream_t on) {
   const Pfa& f = pl.pfa;
   const cd* tws = f.lm >= 11 ? stage_table_compact(f.lm) : stage_table(f.lm);
-  {
+  if (f.rader) {
+    ProfScope ps(this, "k_pfa_rows_rader<11,9,10>", on);
+    PfaRaderArgs a{permuted, quads, Y, f.rd_bhat, f.r1, f.rd_tw2f, f.rd_tw2i, f.rd_tw3f, f.rd_tw3i, f.rd_qidx, f.rd_ridx, f.rowtab,
+                   f.n1, f.n2, f.rows(), G, 1.0f / float(f.n1), 1.0 / double(pl.n)};
+    k_pfa_rows_rader<11, 9, 10><<<dim3(unsigned(G) * unsigned(f.rows())), dim3(256), 0, on>>>(a);
+    PAL_HIP(hipGetLastError());
+  } else {
     char name[48];
     snprintf(name, sizeof name, "k_pfa_rows<%d>", f.lm);
     ProfScope ps(this, name, on);

@@ -1,0 +1,189 @@
+// pfa_rader.h - row pass of the prime-factor route by Rader's algorithm (gfx950, fp64).
+//
+// k_pfa_rows (pfa_kernels.h) computes the N2-point DFTs as chirp convolutions of 2^lm >= 2 N2 - 1 points.  When N2
+// is prime, Rader's re-indexing with a primitive root g of N2,
+//     X[g^r] = x[0] + sum_q x[g^-q] w^(g^(r-q)),      X[0] = sum_k x[k],
+// makes the same DFT a CYCLIC convolution of length L = N2 - 1, and for N2 = 991 that length is 990 = 11 x 9 x 10:
+// two mixed-radix transforms of 990 points (mixed_radix.h) instead of two of 2048, no chirp multiplications, and
+// 35 KB of LDS per workgroup instead of 68.  The rest is the row pass of pfa.hip unchanged: one workgroup per row
+// pair (k1, N1 - k1) of one packed transform, whitened pair spectra built on the fly, tile 1 = the reversed row,
+// column twiddle on the way out, Y[row][m2] to global memory.
+//
+//   prologue   four bins per lane (coalesced), whitened once, scattered into both tiles at q(e) = -log_g e
+//   forward    radix 11, 9 (LDS), then the seam: radix 10, x FFT(w^(g^s)) / (L n), inverse radix 10
+//   inverse    radix 9, 11 (order 10, 9, 11 so that the seam's two butterflies coincide); C[r] lands in LDS
+//   epilogue   four bins per lane: X[e] = x[0] + C[log_g e], column twiddle, coalesced stores
+#pragma once
+#include "conv_kernels.h"
+#include "mixed_radix.h"
+
+namespace pal {
+
+struct PfaRaderArgs {
+  const cd* SP;          // permuted spectra [mic][NR][N2]
+  const int4* quad;      // mic rows (a, b) of pair p and (c, d) of pair q; c < 0: no second pair
+  cd* Y;                 // [G][N1][N2]
+  const cd* bhat;        // FFT_L of w^(g^s), scaled by 1 / (L n)
+  const cd* r1;          // exp(-2 pi i q / N1)
+  const cd *tw2f, *tw2i; // middle-stage twiddles: forward order (radix R2 after R1), inverse order (radix R2 after R3)
+  const cd *tw3f, *tw3i; // last-stage twiddles: forward (radix R3, P = R1 R2), inverse (radix R1, P = R3 R2)
+  const int *qidx, *ridx;   // [N2]: -log_g e mod L and log_g e (entry 0 unused)
+  const int2* rowtab;    // per row of Y: (u1 row mod N1, -)
+  int N1, N2, NR, G;
+  float inv;             // 1 / N1
+  double scale;          // 1 / n: the x[0] and sum terms bypass the scaled convolution
+};
+
+template <int R1, int R2, int R3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_pfa_rows_rader(PfaRaderArgs a) {
+  constexpr int L = R1 * R2 * R3, HALF = 128;
+  static_assert(L / R1 <= HALF && L / R2 <= HALF && L / R3 <= HALF, "one butterfly per lane and stage");
+  __shared__ cd data[2 * L];
+  __shared__ cd tw2f[(R2 - 1) * R1];
+  __shared__ cd tw2i[(R2 - 1) * R3];
+  __shared__ cd part[4][2];            // per wavefront: sum of the tile-0 / tile-1 inputs
+  __shared__ cd dc[2];                 // x[0] of both tiles
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x % a.G, k1 = blockIdx.x / a.G;
+  const int N1 = a.N1, N2 = a.N2;
+  const PlainTile tile{data, L};
+  const int t = tid >> 7, i = tid & (HALF - 1);               // stage work item: tile, butterfly
+
+  // ---- prologue: loads first (tables of the later stages ride along), then whitening and the scatter
+  for (int k = tid; k < (R2 - 1) * R1; k += 256) tw2f[k] = a.tw2f[k];
+  for (int k = tid; k < (R2 - 1) * R3; k += 256) tw2i[k] = a.tw2i[k];
+  const auto* qp = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.quad)) + 4 * g;
+  const int4 q = make_int4(qp[0], qp[1], qp[2], qp[3]);
+  const size_t mic = size_t(a.NR) * N2, off = size_t(k1) * N2;
+  const bool second = q.z >= 0;
+  const cd* sa = a.SP + size_t(q.x) * mic + off;
+  const cd* sb = a.SP + size_t(q.y) * mic + off;
+  const cd* sc = second ? a.SP + size_t(q.z) * mic + off : sa;
+  const cd* sd = second ? a.SP + size_t(q.w) * mic + off : sb;
+  const double keep2 = second ? 1.0 : 0.0;
+  cd va[4], vb[4], vc[4], vd[4];
+  int qi[4], ri[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + 256 * u;
+    const int ee = e < N2 ? e : N2 - 1;
+    va[u] = sa[ee]; vb[u] = sb[ee]; vc[u] = sc[ee]; vd[u] = sd[ee];
+    qi[u] = a.qidx[ee];
+    ri[u] = a.ridx[ee];
+  }
+  const int is = i < L / R3 ? i : 0, ii = i < L / R1 ? i : 0;   // this lane's butterflies of the radix-R3 / radix-R1 stages
+  cd sx = mk(0, 0), sz = mk(0, 0);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + 256 * u;
+    const cd r1 = whiten(va[u], vb[u]);
+    const cd r2 = cscale(whiten(vc[u], vd[u]), keep2);
+    // tile 0: R^p + i R^q at (k1, e);  tile 1: conj(R^p) + i conj(R^q) = the reversed row N1 - k1
+    const cd x = mk(r1.x - r2.y, r1.y + r2.x), z = mk(r1.x + r2.y, r2.x - r1.y);
+    if (e < N2) {
+      sx = sx + x;
+      sz = sz + z;
+      if (e == 0) { dc[0] = x; dc[1] = z; }
+      else { data[qi[u]] = x; data[L + qi[u]] = z; }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sx.x += __shfl_down(sx.x, o, 64); sx.y += __shfl_down(sx.y, o, 64);
+    sz.x += __shfl_down(sz.x, o, 64); sz.y += __shfl_down(sz.y, o, 64);
+  }
+  if ((tid & 63) == 0) { part[tid >> 6][0] = sx; part[tid >> 6][1] = sz; }
+  __syncthreads();
+
+  // ---- forward: radix R1, radix R2
+  {
+    cd v[R1];
+    const bool on = i < L / R1;
+    if (on) mr_load<L, R1, 1, false>(tile, nullptr, t, i, v);
+    __syncthreads();
+    if (on) mr_store<L, R1, 1>(tile, t, i, v);
+    __syncthreads();
+  }
+  {
+    cd v[R2];
+    const bool on = i < L / R2;
+    if (on) mr_load<L, R2, R1, false>(tile, tw2f, t, i, v);
+    __syncthreads();
+    if (on) mr_store<L, R2, R1>(tile, t, i, v);
+    __syncthreads();
+  }
+  // ---- seam: last forward stage (radix R3, outputs i + (L/R3) r), product with the kernel spectrum, first inverse
+  //      stage (radix R3 of the order R3, R2, R1: the same L/R3-strided set of points)
+  {
+    cd v[R3];
+    const bool on = i < L / R3;
+    if (on) {
+      cd f[R3];                                               // (loaded here, not ahead: three wavefronts per SIMD hide the
+#pragma unroll                                                //  latency better than 116 more registers would)
+      for (int r = 1; r < R3; ++r) f[r] = a.tw3f[(r - 1) * (R1 * R2) + is];
+      mr_load_with<L, R3, false>(tile, t, i, v, f);
+#pragma unroll
+      for (int r = 0; r < R3; ++r) v[r] = cmul(v[r], a.bhat[is + (L / R3) * r]);
+      dft_sym<R3, true>(v);
+    }
+    __syncthreads();
+    if (on) mr_store<L, R3, 1>(tile, t, i, v);
+    __syncthreads();
+  }
+  // ---- inverse: radix R2, radix R1
+  {
+    cd v[R2];
+    const bool on = i < L / R2;
+    if (on) mr_load<L, R2, R3, true>(tile, tw2i, t, i, v);
+    __syncthreads();
+    if (on) mr_store<L, R2, R3>(tile, t, i, v);
+    __syncthreads();
+  }
+  {
+    cd v[R1];
+    const bool on = i < L / R1;
+    if (on) {
+      cd f[R1];
+#pragma unroll
+      for (int r = 1; r < R1; ++r) f[r] = a.tw3i[(r - 1) * (R3 * R2) + ii];
+      mr_load_with<L, R1, true>(tile, t, i, v, f);
+    }
+    __syncthreads();
+    if (on) mr_store<L, R1, R3 * R2>(tile, t, i, v);
+    __syncthreads();
+  }
+
+  // ---- epilogue: X[e] = x[0] + C[log_g e] (X[0] = sum of the inputs), column twiddle, store
+  const cd x0 = cscale(dc[0], a.scale), z0 = cscale(dc[1], a.scale);
+  const cd sum0 = cscale(part[0][0] + part[1][0] + part[2][0] + part[3][0], a.scale);
+  const cd sum1 = cscale(part[0][1] + part[1][1] + part[2][1] + part[3][1], a.scale);
+  const int kr = k1 ? N1 - k1 : 0;
+  const auto* rt0 = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.rowtab)) + 2 * k1;
+  const auto* rt1 = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.rowtab)) + 2 * kr;
+  const unsigned uk0 = unsigned(rt0[0]), uk1 = unsigned(rt1[0]), n1 = unsigned(N1);
+  cd* const Y0 = a.Y + (size_t(g) * N1 + k1) * N2;
+  cd* const Y1 = a.Y + (size_t(g) * N1 + kr) * N2;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + 256 * u;
+    if (e >= N2) continue;
+    const cd X = e ? x0 + data[ri[u]] : sum0;
+    const cd Z = e ? z0 + data[L + ri[u]] : sum1;
+    {
+      const unsigned x = __umul24(uk0, unsigned(e));
+      unsigned idx = x - __umul24(unsigned(float(x) * a.inv), n1);
+      idx = min(idx, idx + n1);
+      idx = min(idx, idx - n1);
+      Y0[e] = cmulc(X, a.r1[idx]);                            // r1 holds exp(-2 pi i q / N1)
+    }
+    if (k1) {                                                 // row 0 pairs with itself: tile 1 would be a duplicate
+      const int m2 = e ? N2 - e : 0;
+      const unsigned x = __umul24(uk1, unsigned(m2));
+      unsigned idx = x - __umul24(unsigned(float(x) * a.inv), n1);
+      idx = min(idx, idx + n1);
+      idx = min(idx, idx - n1);
+      Y1[m2] = cmulc(Z, a.r1[idx]);
+    }
+  }
+}
+
+}  // namespace pal

@@ -36,9 +36,9 @@ def test_phat_correlation_matches_numpy(engine, n1, n2):
 
 
 # frame lengths whose n = 2L-1 exercises every shape of the prime-factor route (pfa.hip): one row tile
-# (99 = 1 x 99, 999 = 1 x 999), dense column DFTs with N1 = 9 / 7 / 3 / 11 / 89, tiles of 1024 / 2048 / 4096 points,
+# (99 = 1 x 99, 999 = 1 x 999; 991 = 1 x 991 and 88199 = 89 x 991 take the Rader row pass of pfa_rader.h), dense column DFTs with N1 = 9 / 7 / 3 / 11 / 89, tiles of 1024 / 2048 / 4096 points,
 # and lengths that have no usable split (1999 prime) and stay on the four-step chirp convolution
-PFA_LENGTHS = [(50, 1, 99, 1024), (500, 1, 999, 2048), (1000, 0, 0, 0), (2048, 9, 455, 1024), (2999, 3, 1999, 4096),
+PFA_LENGTHS = [(50, 1, 99, 1024), (496, 1, 991, 2048), (500, 1, 999, 2048), (1000, 0, 0, 0), (2048, 9, 455, 1024), (2999, 3, 1999, 4096),
                (3000, 7, 857, 2048), (5000, 11, 909, 2048), (44100, 89, 991, 2048)]
 
 

@@ -153,7 +153,7 @@ def pfa():
     e4 = Engine(0)
     os.environ["PAL_PFA"] = "1"
     ep = Engine(0)
-    for L in (50, 500, 1000, 2048, 2999, 3000, 5000, 44100):
+    for L in (50, 496, 500, 1000, 2048, 2999, 3000, 5000, 44100):
         a, b = rng.standard_normal(L), rng.standard_normal(L)
         info = ep.plan_info(L)
         got = ep.phat_correlation(a, b)
