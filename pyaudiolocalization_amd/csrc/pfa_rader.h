@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     qi[u] = a.qidx[ee];
     ri[u] = a.ridx[ee];
   }
-  const int is = i < L / R3 ? i : 0, ii = i < L / R1 ? i : 0;   // this lane's butterflies of the radix-R3 / radix-R1 stages
+  const int is = i < L / R3 ? i : 0;                          // this lane's butterfly of the radix-R3 stages
   cd sx = mk(0, 0), sz = mk(0, 0);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -95,12 +95,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   __syncthreads();
 
   // ---- forward: radix R1, radix R2
+  // (the radix-R1 stages have 2 L / R1 = 180 butterflies: packed onto the first three wavefronts, the fourth only waits)
+  const int t1 = tid / (L / R1), i1 = tid % (L / R1);
+  const bool on1 = tid < 2 * (L / R1);
   {
     cd v[R1];
-    const bool on = i < L / R1;
-    if (on) mr_load<L, R1, 1, false>(tile, nullptr, t, i, v);
+    if (on1) mr_load<L, R1, 1, false>(tile, nullptr, t1, i1, v);
     __syncthreads();
-    if (on) mr_store<L, R1, 1>(tile, t, i, v);
+    if (on1) mr_store<L, R1, 1>(tile, t1, i1, v);
     __syncthreads();
   }
   {
@@ -140,15 +142,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   }
   {
     cd v[R1];
-    const bool on = i < L / R1;
-    if (on) {
+    if (on1) {
       cd f[R1];
 #pragma unroll
-      for (int r = 1; r < R1; ++r) f[r] = a.tw3i[(r - 1) * (R3 * R2) + ii];
-      mr_load_with<L, R1, true>(tile, t, i, v, f);
+      for (int r = 1; r < R1; ++r) f[r] = a.tw3i[(r - 1) * (R3 * R2) + i1];
+      mr_load_with<L, R1, true>(tile, t1, i1, v, f);
     }
     __syncthreads();
-    if (on) mr_store<L, R1, R3 * R2>(tile, t, i, v);
+    if (on1) mr_store<L, R1, R3 * R2>(tile, t1, i1, v);
     __syncthreads();
   }
 
@@ -162,27 +163,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   const unsigned uk0 = unsigned(rt0[0]), uk1 = unsigned(rt1[0]), n1 = unsigned(N1);
   cd* const Y0 = a.Y + (size_t(g) * N1 + k1) * N2;
   cd* const Y1 = a.Y + (size_t(g) * N1 + kr) * N2;
+  // twiddle indices u1 row m2 mod N1 of this lane's bins e = tid + 256 u: one reduction, then wave-uniform steps
+  const auto mod_n1 = [&](unsigned x) {                       // x < 2^24: the float quotient is off by at most one
+    unsigned r = x - __umul24(unsigned(float(x) * a.inv), n1);
+    r = min(r, r + n1);
+    return min(r, r - n1);
+  };
+  unsigned idx0 = mod_n1(__umul24(uk0, unsigned(tid)));                        // tile 0: m2 = e
+  unsigned idx1 = mod_n1(__umul24(uk1, unsigned(tid ? N2 - tid : 0)));         // tile 1: m2 = -e mod N2
+  const unsigned st0 = mod_n1(uk0 * 256u), st1 = mod_n1(uk1 * 256u);          // scalar
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int e = tid + 256 * u;
-    if (e >= N2) continue;
-    const cd X = e ? x0 + data[ri[u]] : sum0;
-    const cd Z = e ? z0 + data[L + ri[u]] : sum1;
-    {
-      const unsigned x = __umul24(uk0, unsigned(e));
-      unsigned idx = x - __umul24(unsigned(float(x) * a.inv), n1);
-      idx = min(idx, idx + n1);
-      idx = min(idx, idx - n1);
-      Y0[e] = cmulc(X, a.r1[idx]);                            // r1 holds exp(-2 pi i q / N1)
+    if (e < N2) {
+      const cd X = e ? x0 + data[ri[u]] : sum0;
+      const cd Z = e ? z0 + data[L + ri[u]] : sum1;
+      Y0[e] = cmulc(X, a.r1[idx0]);                           // r1 holds exp(-2 pi i q / N1)
+      if (k1) Y1[e ? N2 - e : 0] = cmulc(Z, a.r1[idx1]);      // row 0 pairs with itself: tile 1 would be a duplicate
     }
-    if (k1) {                                                 // row 0 pairs with itself: tile 1 would be a duplicate
-      const int m2 = e ? N2 - e : 0;
-      const unsigned x = __umul24(uk1, unsigned(m2));
-      unsigned idx = x - __umul24(unsigned(float(x) * a.inv), n1);
-      idx = min(idx, idx + n1);
-      idx = min(idx, idx - n1);
-      Y1[m2] = cmulc(Z, a.r1[idx]);
-    }
+    idx0 += st0;
+    idx0 = min(idx0, idx0 - n1);
+    idx1 = (u == 0 && tid == 0) ? mod_n1(__umul24(uk1, unsigned(N2 - 256))) : idx1 + n1 - st1;   // (e = 0 maps to m2 = 0, not N2)
+    idx1 = min(idx1, idx1 - n1);
   }
 }
 
