@@ -546,6 +546,7 @@ __global__ __launch_bounds__(kT) void k_peak_pivots(PeakArgs a) {
   const int row = blockIdx.x;
   const double* c = a.corr + size_t(row) * a.stride;
   const int n = a.n;
+  if (tid == 0) a.gcount[row] = 0;      // the row's bracket list starts empty (the stream launch behind this one fills it)
   constexpr int kRuns = kSample / kT;
   const int ns = n < kSample ? n : kSample;
   double sv[kRuns];
@@ -939,7 +940,7 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
   a.tiles_per_seg = (ntiles + want - 1) / want;
   if (a.tiles_per_seg > kMaxTilesPerSeg) a.tiles_per_seg = kMaxTilesPerSeg;   // the segment's bracket values must fit its LDS list
   a.splits = (ntiles + a.tiles_per_seg - 1) / a.tiles_per_seg;
-  // per-stream scratch: [gcount | pre | parts | glist]; the list fills are zeroed in front of every launch
+  // per-stream scratch: [gcount | pre | parts | glist]; the pivot launch zeroes the list fills
   size_t off_pre = (size_t(rows) * sizeof(int) + 127) & ~size_t(127);
   size_t off_parts = (off_pre + size_t(rows) * sizeof(RowPre) + 127) & ~size_t(127);
   size_t off_list = (off_parts + size_t(rows) * a.splits * sizeof(Partial) + 127) & ~size_t(127);
@@ -951,7 +952,6 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
   a.pre = reinterpret_cast<RowPre*>(base + off_pre);
   a.parts = reinterpret_cast<Partial*>(base + off_parts);
   a.glist = reinterpret_cast<double*>(base + off_list);
-  PAL_HIP(hipMemsetAsync(a.gcount, 0, size_t(rows) * sizeof(int), on));
   {
     ProfScope ps(this, "k_peak_pivots", on);
     k_peak_pivots<<<dim3(rows), dim3(kT), 0, on>>>(a);

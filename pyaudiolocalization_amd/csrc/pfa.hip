@@ -221,7 +221,7 @@ int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads
   if (f.rader) {
     ProfScope ps(this, "k_pfa_rows_rader<11,9,10>", on);
     PfaRaderArgs a{permuted, quads, Y, f.rd_bhat, f.r1, f.rd_tw2f, f.rd_tw2i, f.rd_tw3f, f.rd_tw3i, f.rd_qidx, f.rd_ridx, f.rowtab,
-                   f.n1, f.n2, f.rows(), G, 1.0f / float(f.n1), 1.0 / double(pl.n)};
+                   f.n1, f.n2, f.rows(), G, 1.0f / float(f.n1), 1.0 / double(pl.n), nullptr};
     k_pfa_rows_rader<11, 9, 10><<<dim3(unsigned(G) * unsigned(f.rows())), dim3(256), 0, on>>>(a);
     PAL_HIP(hipGetLastError());
   } else {

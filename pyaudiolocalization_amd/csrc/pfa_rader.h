@@ -32,6 +32,7 @@ struct PfaRaderArgs {
   int N1, N2, NR, G;
   float inv;             // 1 / N1
   double scale;          // 1 / n: the x[0] and sum terms bypass the scaled convolution
+  unsigned long long* stamps;   // diagnostics only (tools/microbench_pfa): 100 MHz clock reads of lane 0 per phase
 };
 
 template <int R1, int R2, int R3>
@@ -48,6 +49,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   const int N1 = a.N1, N2 = a.N2;
   const PlainTile tile{data, L};
   const int t = tid >> 7, i = tid & (HALF - 1);               // stage work item: tile, butterfly
+  unsigned long long* const stamps = a.stamps;
+  int stamp_at = 0;
+  auto stamp = [&]() {
+    if (stamps && tid == 0) stamps[size_t(blockIdx.x) * 8 + stamp_at] = __builtin_amdgcn_s_memrealtime();
+    ++stamp_at;
+  };
+  stamp();
 
   // ---- prologue: loads first (tables of the later stages ride along), then whitening and the scatter
   for (int k = tid; k < (R2 - 1) * R1; k += 256) tw2f[k] = a.tw2f[k];
@@ -93,6 +101,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   }
   if ((tid & 63) == 0) { part[tid >> 6][0] = sx; part[tid >> 6][1] = sz; }
   __syncthreads();
+  stamp();
 
   // ---- forward: radix R1, radix R2
   // (the radix-R1 stages have 2 L / R1 = 180 butterflies: packed onto the first three wavefronts, the fourth only waits)
@@ -113,6 +122,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     if (on) mr_store<L, R2, R1>(tile, t, i, v);
     __syncthreads();
   }
+  stamp();
   // ---- seam: last forward stage (radix R3, outputs i + (L/R3) r), product with the kernel spectrum, first inverse
   //      stage (radix R3 of the order R3, R2, R1: the same L/R3-strided set of points)
   {
@@ -131,6 +141,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     if (on) mr_store<L, R3, 1>(tile, t, i, v);
     __syncthreads();
   }
+  stamp();
   // ---- inverse: radix R2, radix R1
   {
     cd v[R2];
@@ -153,6 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     __syncthreads();
   }
 
+  stamp();
   // ---- epilogue: X[e] = x[0] + C[log_g e] (X[0] = sum of the inputs), column twiddle, store
   const cd x0 = cscale(dc[0], a.scale), z0 = cscale(dc[1], a.scale);
   const cd sum0 = cscale(part[0][0] + part[1][0] + part[2][0] + part[3][0], a.scale);
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     idx1 = (u == 0 && tid == 0) ? mod_n1(__umul24(uk1, unsigned(N2 - 256))) : idx1 + n1 - st1;   // (e = 0 maps to m2 = 0, not N2)
     idx1 = min(idx1, idx1 - n1);
   }
+  stamp();
 }
 
 }  // namespace pal

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "pfa_kernels.h"
+#include "pfa_rader.h"
 
 using namespace pal;
 
@@ -368,6 +369,38 @@ int main(int argc, char** argv) {
     unsigned long long t0 = ~0ull, t1 = 0;
     for (unsigned w = 0; w < grid; ++w) { t0 = std::min(t0, hs[size_t(w) * 8]); t1 = std::max(t1, hs[size_t(w) * 8 + 4]); }
     printf("  rows launch span %.1f us\n", double(t1 - t0) / 100.0);
+  }
+  {   // Rader row pass: random but valid tables (timing only)
+    constexpr int LR = 990;
+    int *qidx, *ridx;
+    cd *bhat, *t2f, *t2i, *t3f, *t3i;
+    CHECK(hipMalloc(&qidx, sizeof(int) * N2));
+    CHECK(hipMalloc(&ridx, sizeof(int) * N2));
+    std::vector<int> perm(N2);
+    for (int e = 0; e < N2; ++e) perm[e] = e ? (e * 7) % LR : 0;
+    CHECK(hipMemcpy(qidx, perm.data(), sizeof(int) * N2, hipMemcpyHostToDevice));
+    for (int e = 0; e < N2; ++e) perm[e] = e ? (e * 13) % LR : 0;
+    CHECK(hipMemcpy(ridx, perm.data(), sizeof(int) * N2, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&bhat, sizeof(cd) * 1024)); CHECK(hipMalloc(&t2f, sizeof(cd) * 1024)); CHECK(hipMalloc(&t2i, sizeof(cd) * 1024));
+    CHECK(hipMalloc(&t3f, sizeof(cd) * 1024)); CHECK(hipMalloc(&t3i, sizeof(cd) * 1024));
+    for (cd* p : {bhat, t2f, t2i, t3f, t3i}) CHECK(hipMemcpy(p, rnd.data(), sizeof(cd) * 1024, hipMemcpyHostToDevice));
+    unsigned long long* st;
+    CHECK(hipMalloc(&st, sizeof(unsigned long long) * 8 * grid));
+    PfaRaderArgs ra{SP, quad, Y, bhat, r1, t2f, t2i, t3f, t3i, qidx, ridx, rowtab, N1, N2, NR, G, 1.0f / float(N1), 1.0 / double(n), nullptr};
+    time_it("rows (Rader 11 x 9 x 10): product", 20, [&] { k_pfa_rows_rader<11, 9, 10><<<dim3(grid), dim3(256)>>>(ra); });
+    ra.stamps = st;
+    k_pfa_rows_rader<11, 9, 10><<<dim3(grid), dim3(256)>>>(ra);
+    CHECK(hipDeviceSynchronize());
+    std::vector<unsigned long long> hs(size_t(8) * grid);
+    CHECK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
+    const char* names[6] = {"loads + whiten + scatter", "forward radix 11, 9", "seam", "inverse radix 9, 11", "epilogue", "total"};
+    for (int ph = 0; ph < 6; ++ph) {
+      std::vector<double> d(grid);
+      for (unsigned w = 0; w < grid; ++w)
+        d[w] = ph < 5 ? double(hs[size_t(w) * 8 + ph + 1] - hs[size_t(w) * 8 + ph]) / 100.0 : double(hs[size_t(w) * 8 + 5] - hs[size_t(w) * 8]) / 100.0;
+      std::sort(d.begin(), d.end());
+      printf("  rader phase %-26s median %6.2f us  p90 %6.2f us\n", names[ph], d[grid / 2], d[grid * 9 / 10]);
+    }
   }
   const dim3 cg(unsigned(G) * nblk, 1);
   time_it("cols: product", 20, [&] { k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
