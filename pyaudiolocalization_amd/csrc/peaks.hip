@@ -31,7 +31,11 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "engine.h"
 #include "reduce.h"
@@ -77,6 +81,7 @@ struct PeakArgs {
   Partial* parts;                        // [rows][splits]
   double* glist;                         // [rows][kList] bracket values
   int* gcount;                           // [rows] fill of glist (> kList: overflow, the finish kernel re-reads the row)
+  unsigned long long* stamps;            // diagnostics (PAL_DEBUG_STAMPS=1): [rows][8] 100 MHz clock reads of the finish launch
 };
 
 struct Shared {                          // pivot and finish kernels
@@ -773,6 +778,12 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   const RowPre pre = load_pre(a.pre, row);
   const double k0 = pre.k0, ka = pre.ka, lo = pre.lo, hi = pre.hi;
   const unsigned r1 = unsigned((n - 1) / 2), r2 = unsigned(n / 2);   // ranks of the median's one or two order statistics
+  int stamp_at = 0;
+  auto stamp = [&]() {
+    if (a.stamps && tid == 0) a.stamps[size_t(row) * 8 + stamp_at] = __builtin_amdgcn_s_memrealtime();
+    ++stamp_at;
+  };
+  stamp();
 
   // ---- merge the segments (every lane the same loop: no broadcast needed) ----
   int imax = -1, imin = -1, mb = -1;
@@ -786,6 +797,7 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
     s1 += pt.s1; s2 += pt.s2; a1 += pt.a1; a2 += pt.a2;
     below += pt.below;
   }
+  stamp();
   const int cnt = want_median ? a.gcount[row] : 0;
   const double* list = a.glist + size_t(row) * kList;
   const double mean_abs = ka + a1 / double(n);                 // np.mean(np.abs(corr)) (utils.py:155)
@@ -824,6 +836,7 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   if (var < 0) var = 0;
   const double noise = sqrt(var);
   const double snr = noise == 0.0 ? INFINITY : vmax / noise;
+  stamp();
 
   if (a.method < 0) {                                          // metrics only (pal_corr_metrics)
     if (tid == 0) {
@@ -854,6 +867,7 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
     thr1 = a.mult * (mean_abs + sqrt(va));                     // mean + std of |corr| (utils.py:147)
   }
 
+  stamp();
   // ---- fallback chain (utils.py:152-179) ----
   int branch = 0;
   int sel[PAL_MAX_PEAKS];
@@ -889,6 +903,7 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
     }
   }
   if (argmax_fallback || overflow) { sel[0] = imax; selh[0] = vmax; count = 1; }
+  stamp();
 
   if (tid == 0) {
     pal_pair_record r;
@@ -962,9 +977,31 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
     k_peak_stream<<<dim3(unsigned(rows) * unsigned(a.splits)), dim3(kTS), 0, on>>>(a);
     PAL_HIP(hipGetLastError());
   }
-  ProfScope ps(this, metrics_only ? "k_peak_finish(metrics)" : "k_peak_finish", on);
-  k_peak_finish<<<dim3(rows), dim3(kT), 0, on>>>(a, table, ksel_multi, status);
-  return check(hipGetLastError(), "k_peak_finish");
+  a.stamps = nullptr;
+  static const bool want_stamps = getenv("PAL_DEBUG_STAMPS") != nullptr;
+  if (want_stamps) {
+    void* st = nullptr;
+    PAL_TRY(scratch(13, size_t(rows) * 8 * sizeof(unsigned long long), &st));
+    a.stamps = static_cast<unsigned long long*>(st);
+  }
+  {
+    ProfScope ps(this, metrics_only ? "k_peak_finish(metrics)" : "k_peak_finish", on);
+    k_peak_finish<<<dim3(rows), dim3(kT), 0, on>>>(a, table, ksel_multi, status);
+    PAL_HIP(hipGetLastError());
+  }
+  if (want_stamps && !metrics_only) {      // diagnostics: median phase times of this launch (synchronises)
+    std::vector<unsigned long long> h(size_t(rows) * 8);
+    PAL_HIP(hipStreamSynchronize(on));
+    PAL_HIP(hipMemcpy(h.data(), a.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const char* names[4] = {"merge", "snr window", "threshold", "select"};
+    std::vector<double> d(rows);
+    for (int ph = 0; ph < 4; ++ph) {
+      for (int r = 0; r < rows; ++r) d[r] = double(h[size_t(r) * 8 + ph + 1] - h[size_t(r) * 8 + ph]) / 100.0;
+      std::sort(d.begin(), d.end());
+      fprintf(stderr, "[pal] k_peak_finish %-10s median %6.2f us  p90 %6.2f us  max %6.2f us\n", names[ph], d[rows / 2], d[rows * 9 / 10], d[rows - 1]);
+    }
+  }
+  return PAL_OK;
 }
 
 }  // namespace pal

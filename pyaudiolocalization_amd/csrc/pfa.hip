@@ -174,6 +174,7 @@ int Engine::build_rader(Pfa& f, long long n, long long u2) {
     ridx[gpow[s]] = s;                                         // X[g^s] = x[0] + C[s]
     qidx[gpow[(L - s) % L]] = s;                               // a[s] = x[g^-s]
   }
+  qidx[0] = L;                                                 // the rows of SP keep this order, bin 0 last
   const long double two_pi = 6.283185307179586476925286766559005768L;
   std::vector<long double> br(L), bi(L);
   for (int s = 0; s < L; ++s) {
@@ -220,7 +221,7 @@ int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads
   const cd* tws = f.lm >= 11 ? stage_table_compact(f.lm) : stage_table(f.lm);
   if (f.rader) {
     ProfScope ps(this, "k_pfa_rows_rader<11,9,10>", on);
-    PfaRaderArgs a{permuted, quads, Y, f.rd_bhat, f.r1, f.rd_tw2f, f.rd_tw2i, f.rd_tw3f, f.rd_tw3i, f.rd_qidx, f.rd_ridx, f.rowtab,
+    PfaRaderArgs a{permuted, quads, Y, f.rd_bhat, f.r1, f.rd_tw2f, f.rd_tw2i, f.rd_tw3f, f.rd_tw3i, f.rd_ridx, f.rowtab,
                    f.n1, f.n2, f.rows(), G, 1.0f / float(f.n1), 1.0 / double(pl.n), nullptr};
     k_pfa_rows_rader<11, 9, 10><<<dim3(unsigned(G) * unsigned(f.rows())), dim3(256), 0, on>>>(a);
     PAL_HIP(hipGetLastError());

@@ -9,25 +9,29 @@
 // pair (k1, N1 - k1) of one packed transform, whitened pair spectra built on the fly, tile 1 = the reversed row,
 // column twiddle on the way out, Y[row][m2] to global memory.
 //
-//   prologue   four bins per lane (coalesced), whitened once, scattered into both tiles at q(e) = -log_g e
-//   forward    radix 11, 9 (LDS), then the seam: radix 10, x FFT(w^(g^s)) / (L n), inverse radix 10
+//   forward    the rows of SP are stored in generator order (position q(e) = -log_g e, bin 0 last: the forward
+//              transform's storer writes them that way), so the radix-11 stage reads its inputs coalesced from
+//              global memory: the two halves of a wavefront own butterfly i of tile 0 and of tile 1, each half
+//              whitens six of the eleven (shared) inputs and the halves trade with v_permlane32_swap;
+//              radix 9 (LDS), then the seam: radix 10, x FFT(w^(g^s)) / (L n), inverse radix 10
 //   inverse    radix 9, 11 (order 10, 9, 11 so that the seam's two butterflies coincide); C[r] lands in LDS
 //   epilogue   four bins per lane: X[e] = x[0] + C[log_g e], column twiddle, coalesced stores
 #pragma once
 #include "conv_kernels.h"
 #include "mixed_radix.h"
+#include "pfa_kernels.h"   // swap_pair
 
 namespace pal {
 
 struct PfaRaderArgs {
-  const cd* SP;          // permuted spectra [mic][NR][N2]
+  const cd* SP;          // permuted spectra [mic][NR][N2], rows in generator order: x[g^-s] at s < L, x[0] at L
   const int4* quad;      // mic rows (a, b) of pair p and (c, d) of pair q; c < 0: no second pair
   cd* Y;                 // [G][N1][N2]
   const cd* bhat;        // FFT_L of w^(g^s), scaled by 1 / (L n)
   const cd* r1;          // exp(-2 pi i q / N1)
   const cd *tw2f, *tw2i; // middle-stage twiddles: forward order (radix R2 after R1), inverse order (radix R2 after R3)
   const cd *tw3f, *tw3i; // last-stage twiddles: forward (radix R3, P = R1 R2), inverse (radix R1, P = R3 R2)
-  const int *qidx, *ridx;   // [N2]: -log_g e mod L and log_g e (entry 0 unused)
+  const int* ridx;       // [N2]: log_g e (entry 0 unused)
   const int2* rowtab;    // per row of Y: (u1 row mod N1, -)
   int N1, N2, NR, G;
   float inv;             // 1 / N1
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   };
   stamp();
 
-  // ---- prologue: loads first (tables of the later stages ride along), then whitening and the scatter
+  // ---- tables of the later stages, then the first forward stage straight from global memory
   for (int k = tid; k < (R2 - 1) * R1; k += 256) tw2f[k] = a.tw2f[k];
   for (int k = tid; k < (R2 - 1) * R3; k += 256) tw2i[k] = a.tw2i[k];
   const auto* qp = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.quad)) + 4 * g;
@@ -69,51 +73,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   const cd* sc = second ? a.SP + size_t(q.z) * mic + off : sa;
   const cd* sd = second ? a.SP + size_t(q.w) * mic + off : sb;
   const double keep2 = second ? 1.0 : 0.0;
-  cd va[4], vb[4], vc[4], vd[4];
-  int qi[4], ri[4];
+  int ri[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int e = tid + 256 * u;
-    const int ee = e < N2 ? e : N2 - 1;
-    va[u] = sa[ee]; vb[u] = sb[ee]; vc[u] = sc[ee]; vd[u] = sd[ee];
-    qi[u] = a.qidx[ee];
-    ri[u] = a.ridx[ee];
+    ri[u] = a.ridx[e < N2 ? e : N2 - 1];
   }
   const int is = i < L / R3 ? i : 0;                          // this lane's butterfly of the radix-R3 stages
-  cd sx = mk(0, 0), sz = mk(0, 0);
+  // tile 0: R^p + i R^q at (k1, e);  tile 1: conj(R^p) + i conj(R^q) = the reversed row N1 - k1, held at the SAME
+  // positions (it is transformed as the reversed sequence and its outputs are stored reversed)
+  constexpr int NB1 = L / R1, HR = (R1 + 1) / 2;              // 90 butterflies per tile, 6 inputs per half-wavefront
+  static_assert(NB1 <= 96 && 2 * HR >= R1, "three wavefronts of 32 butterfly pairs");
+  if (tid < 192) {                                            // (wave-uniform)
+    const int upper = (tid >> 5) & 1, bf = 32 * (tid >> 6) + (tid & 31);
+    const int bfc = bf < NB1 ? bf : NB1 - 1;
+    cd va[HR], vb[HR], vc[HR], vd[HR];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int e = tid + 256 * u;
-    const cd r1 = whiten(va[u], vb[u]);
-    const cd r2 = cscale(whiten(vc[u], vd[u]), keep2);
-    // tile 0: R^p + i R^q at (k1, e);  tile 1: conj(R^p) + i conj(R^q) = the reversed row N1 - k1
-    const cd x = mk(r1.x - r2.y, r1.y + r2.x), z = mk(r1.x + r2.y, r2.x - r1.y);
-    if (e < N2) {
-      sx = sx + x;
-      sz = sz + z;
-      if (e == 0) { dc[0] = x; dc[1] = z; }
-      else { data[qi[u]] = x; data[L + qi[u]] = z; }
+    for (int u = 0; u < HR; ++u) {
+      const int j = upper * HR + u;
+      const int at = bfc + NB1 * (j < R1 ? j : R1 - 1);
+      va[u] = sa[at]; vb[u] = sb[at]; vc[u] = sc[at]; vd[u] = sd[at];
     }
+    cd v[2 * HR];
+    cd sx = mk(0, 0), sz = mk(0, 0);
+#pragma unroll
+    for (int u = 0; u < HR; ++u) {
+      const cd r1 = whiten(va[u], vb[u]);
+      const cd r2 = cscale(whiten(vc[u], vd[u]), keep2);
+      const cd x = mk(r1.x - r2.y, r1.y + r2.x), z = mk(r1.x + r2.y, r2.x - r1.y);
+      if (bf < NB1 && upper * HR + u < R1) { sx = sx + x; sz = sz + z; }
+      // lower half: v[u] = own x, v[HR + u] = the upper half's x;  upper half: v[u] = the lower half's z, v[HR + u] = own z
+      swap_pair(x.x, z.x, v[u].x, v[HR + u].x);
+      swap_pair(x.y, z.y, v[u].y, v[HR + u].y);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      sx.x += __shfl_down(sx.x, o, 64); sx.y += __shfl_down(sx.y, o, 64);
+      sz.x += __shfl_down(sz.x, o, 64); sz.y += __shfl_down(sz.y, o, 64);
+    }
+    if ((tid & 63) == 0) { part[tid >> 6][0] = sx; part[tid >> 6][1] = sz; }
+    dft_sym<R1, false>(v);
+    if (bf < NB1) mr_store<L, R1, 1>(tile, upper, bf, v);
+  } else if (tid == 192) {                                    // bin 0 (the row's last position) bypasses the convolution
+    const cd r1 = whiten(sa[L], sb[L]);
+    const cd r2 = cscale(whiten(sc[L], sd[L]), keep2);
+    const cd x = mk(r1.x - r2.y, r1.y + r2.x), z = mk(r1.x + r2.y, r2.x - r1.y);
+    dc[0] = x; dc[1] = z;
+    part[3][0] = x; part[3][1] = z;
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    sx.x += __shfl_down(sx.x, o, 64); sx.y += __shfl_down(sx.y, o, 64);
-    sz.x += __shfl_down(sz.x, o, 64); sz.y += __shfl_down(sz.y, o, 64);
-  }
-  if ((tid & 63) == 0) { part[tid >> 6][0] = sx; part[tid >> 6][1] = sz; }
   __syncthreads();
   stamp();
 
-  // ---- forward: radix R1, radix R2
+  // ---- forward: radix R2
   // (the radix-R1 stages have 2 L / R1 = 180 butterflies: packed onto the first three wavefronts, the fourth only waits)
   const int t1 = tid / (L / R1), i1 = tid % (L / R1);
   const bool on1 = tid < 2 * (L / R1);
-  {
-    cd v[R1];
-    if (on1) mr_load<L, R1, 1, false>(tile, nullptr, t1, i1, v);
-    __syncthreads();
-    if (on1) mr_store<L, R1, 1>(tile, t1, i1, v);
-    __syncthreads();
-  }
   {
     cd v[R2];
     const bool on = i < L / R2;
