@@ -165,13 +165,34 @@ struct CorrStorer {
   size_t stride;
   int n;
   const cd* w;
+  const int* zero_rows;   // per row: 1 = a microphone of the pair is silent and the row is exactly zero (k_pair_zero); or null
   __device__ void operator()(int g, unsigned j, cd y) const {
     if (j >= (unsigned)n) return;
     const cd z = cmul(y, w[j]);
-    corr[size_t(2 * g) * stride + j] = z.x;
-    corr[size_t(2 * g + 1) * stride + j] = z.y;
+    corr[size_t(2 * g) * stride + j] = zero_rows && zero_rows[2 * g] ? 0.0 : z.x;
+    corr[size_t(2 * g + 1) * stride + j] = zero_rows && zero_rows[2 * g + 1] ? 0.0 : z.y;
   }
 };
+
+// Silent channels.  A frame of zeros has a zero spectrum, R = 0 / (0 + 1e-10) = 0 in every bin, and the reference's
+// correlation row is exactly zero (argmax 0, no peaks).  Here two pairs share one complex transform, whose rounding
+// leaves 1e-17 of the OTHER pair in that row: the rows of pairs with a silent microphone are therefore forced to zero.
+__global__ __launch_bounds__(256) void k_row_nonzero(const double* __restrict__ frames, size_t frame_stride, int len, int* __restrict__ flags) {
+  const double* x = frames + size_t(blockIdx.x) * frame_stride;
+  bool any = false;
+  for (int i = threadIdx.x; i < len; i += 256) any = any || x[i] != 0.0;
+  const int all = __syncthreads_or(any ? 1 : 0);
+  if (threadIdx.x == 0) flags[blockIdx.x] = all;
+}
+
+__global__ __launch_bounds__(256) void k_pair_zero(const int4* __restrict__ quads, const int* __restrict__ nonzero, int64_t ntr,
+                                                   int* __restrict__ zero_rows) {
+  const int64_t g = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (g >= ntr) return;
+  const int4 q = quads[g];
+  zero_rows[2 * g] = !nonzero[q.x] || !nonzero[q.y];
+  zero_rows[2 * g + 1] = q.z >= 0 && (!nonzero[q.z] || !nonzero[q.w]);
+}
 
 // ------------------------------------------------------------------ plans
 const cd* Engine::stage_table(int ln) {
@@ -274,9 +295,13 @@ int Engine::get_plan(int n, int lin, int nout, Plan** out) {
 }
 
 // ------------------------------------------------------------------ pipelines
-int Engine::forward_spectra(Plan& pl, const double* frames, size_t frame_stride, int rows, int len, cd* spectra) {
+int Engine::forward_spectra(Plan& pl, const double* frames, size_t frame_stride, int rows, int len, cd* spectra, int* nonzero) {
   Engine* e = this;
   if (len > pl.lin) return fail(PAL_ERR_INVALID, "frame length %d exceeds plan input length %d", len, pl.lin);
+  if (nonzero && rows > 0) {
+    k_row_nonzero<<<dim3(rows), dim3(256), 0, stream>>>(frames, frame_stride, len, nonzero);
+    PAL_HIP(hipGetLastError());
+  }
   const Conv& c = pl.fwd;
   void* wsp = nullptr;
   PAL_TRY(scratch(0, size_t(chunk) * c.M() * sizeof(cd), &wsp));
@@ -301,7 +326,7 @@ int Engine::forward_spectra(Plan& pl, const double* frames, size_t frame_stride,
 
 int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4* quads, int64_t npairs, int n2,
                               const pal_phat_params& prm, pal_pair_record* table, int32_t* ksel_multi,
-                              double* corr_out) {
+                              double* corr_out, const int* nonzero) {
   Engine* e = this;
   const Conv& c = pl.inv;
   const int n = pl.n;
@@ -324,6 +349,14 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
   PAL_TRY(scratch(1, size_t(nslot > 2 ? nslot : 2) * buf_doubles * sizeof(double), &p));
   double* cbuf = static_cast<double*>(p);
   const int64_t ntr = (npairs + 1) / 2;
+  int* zero_rows = nullptr;
+  if (nonzero && ntr > 0) {
+    void* zp = nullptr;
+    PAL_TRY(scratch(14, size_t(2 * ntr) * sizeof(int), &zp));
+    zero_rows = static_cast<int*>(zp);
+    k_pair_zero<<<dim3(unsigned((ntr + 255) / 256)), dim3(256), 0, stream>>>(quads, nonzero, ntr, zero_rows);
+    PAL_HIP(hipGetLastError());
+  }
   if (two || split) {   // the other streams start after everything already queued on `stream` (spectra, pair table)
     PAL_HIP(hipEventRecord(ev_corr[0], stream));
     PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[0], 0));
@@ -342,17 +375,22 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     const bool via_scratch = !corr_out || rows < 2 * G;
     double* crow = via_scratch ? cbuf + size_t(slot) * buf_doubles : corr_out + size_t(p0) * stride;
     if (split && group >= 2) PAL_HIP(hipStreamWaitEvent(stream, ev_peaks[slot], 0));   // group - 2 is done with this buffer
-    if (pfa) {
+    const bool fused = pfa && table && !split && pfa_sub == 0 && pfa_can_fuse(pl);
+    if (fused) {
+      PAL_TRY(pfa_pair_group_fused(pl, permuted, quads + t0, G, rows, Wg, crow, stride, zero_rows ? zero_rows + p0 : nullptr, prm, n2, table + p0,
+                                   ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr, on));
+    } else if (pfa) {
       // sub-groups: the Y of a sub-group (1.4 MB per transform) is still in the Infinity Cache when the column
       // pass reads it back, while the peak kernels keep whole launch groups (their fixed costs want many rows)
       const int sub = pfa_sub > 0 && pfa_sub < G ? pfa_sub : G;
       for (int g0 = 0; g0 < G; g0 += sub) {
         const int Gs = G - g0 < sub ? G - g0 : sub;
-        PAL_TRY(pfa_pair_group(pl, permuted, quads + t0 + g0, Gs, Wg, crow + size_t(2 * g0) * stride, stride, on));
+        PAL_TRY(pfa_pair_group(pl, permuted, quads + t0 + g0, Gs, Wg, crow + size_t(2 * g0) * stride, stride,
+                               zero_rows ? zero_rows + p0 + 2 * g0 : nullptr, on));
       }
     } else {
       PairLoader ld{spectra, quads + t0, n, pl.H, pl.w};
-      CorrStorer st{crow, stride, n, pl.w};
+      CorrStorer st{crow, stride, n, pl.w, zero_rows ? zero_rows + p0 : nullptr};
       PAL_TRY(launch_cols_fwd(e, c, G, ld, Wg, on));
       PAL_TRY(launch_rows(e, c, G, Wg, true, 1.0, on));
       PAL_TRY(launch_cols_inv(e, c, G, Wg, st, on));
@@ -366,7 +404,7 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
       PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[slot], 0));
       pon = stream2;
     }
-    if (table)
+    if (table && !fused)
       PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr, pon));
     if (split) PAL_HIP(hipEventRecord(ev_peaks[slot], stream2));
   }

@@ -17,6 +17,9 @@ namespace pal {
 
 // One circular convolution of length M = M1 x M2 (four-step, both factors in LDS).
 // M2 = 2^l2; M1 = 2^l1, or 3 * 2^l1 (r3) when the 3 * 2^k length is the smaller fit.
+struct PeakArgs;    // peak_types.h
+struct PfaSample;   // pfa_sample.h
+
 struct Conv {
   int l1 = 0, l2 = 0;
   bool r3 = false;
@@ -118,7 +121,7 @@ struct Engine {
   void free_pfa(Pfa& f);
   int build_rader(Pfa& f, long long n, long long u2);   // pfa.hip: Rader tables when N2 is 991
   int pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, double* corr, size_t stride,
-                     hipStream_t on);
+                     const int* zero_rows, hipStream_t on);
   int get_plan(int n, int lin, int nout, Plan** out);
   int alloc_conv(Conv& c, size_t needed);   // geometry, tables and chirp-spectrum storage for >= `needed` points
   void free_conv(Conv& c);
@@ -130,11 +133,25 @@ struct Engine {
   void prof_flush();
 
   // pipelines (all pointers are device pointers)
-  int forward_spectra(Plan& pl, const double* frames, size_t frame_stride, int rows, int len, cd* spectra);
+  int forward_spectra(Plan& pl, const double* frames, size_t frame_stride, int rows, int len, cd* spectra, int* nonzero = nullptr);
   int pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4* quads, int64_t npairs, int n2,
-                        const pal_phat_params& prm, pal_pair_record* table, int32_t* ksel_multi, double* corr_out);
+                        const pal_phat_params& prm, pal_pair_record* table, int32_t* ksel_multi, double* corr_out,
+                        const int* nonzero = nullptr);
   int peaks(const double* corr, size_t stride, int rows, int n, int n2, const pal_phat_params& prm,
             pal_pair_record* table, int32_t* ksel_multi, hipStream_t on);
+  // the same in pieces, for the column pass that produces the streaming statistics itself (pfa_cols_stats.h):
+  // arguments + scratch (segments = `blocks` column blocks of a grid with rows of grid_n2), pivots from the grid,
+  // [the caller's fused column launch], the finish launch
+  int peaks_setup(const double* corr, size_t stride, int rows, int n, int n2, const pal_phat_params& prm, int blocks, int grid_n2,
+                  hipStream_t on, PeakArgs& a);
+  int peaks_pivots_grid(const PeakArgs& a, int rows, const PfaSample& sp, hipStream_t on);
+  int peaks_finish(PeakArgs& a, int rows, pal_pair_record* table, int32_t* ksel_multi, hipStream_t on);
+  int pfa_rows(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, hipStream_t on);
+  bool pfa_can_fuse(const Plan& pl) const;
+  int pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, double* corr, size_t stride,
+                           const int* zero_rows, const pal_phat_params& prm, int n2, pal_pair_record* table, int32_t* ksel_multi,
+                           hipStream_t on);
+  bool fuse_peaks = true;     // PAL_FUSED=0: separate column pass and peak stream even where the fused launch applies
 };
 
 struct ProfScope {

@@ -148,9 +148,10 @@ static int all_pairs_dev(Engine* e, const double* d_frames, int B, int M, int L,
   PAL_TRY(e->get_plan(2 * L - 1, L, 2 * L - 1, &pl));
   const int rows = B * M;
   void* sp = nullptr;
-  PAL_TRY(e->scratch(2, size_t(rows) * pl->spec_stride() * sizeof(cd), &sp));
+  PAL_TRY(e->scratch(2, size_t(rows) * pl->spec_stride() * sizeof(cd) + size_t(rows) * sizeof(int), &sp));
   cd* spectra = static_cast<cd*>(sp);
-  PAL_TRY(e->forward_spectra(*pl, d_frames, size_t(L), rows, L, spectra));
+  int* nonzero = reinterpret_cast<int*>(spectra + size_t(rows) * pl->spec_stride());   // per frame row: any non-zero sample
+  PAL_TRY(e->forward_spectra(*pl, d_frames, size_t(L), rows, L, spectra, nonzero));
   // the pair table depends on (B, M) only: keep it on the device between calls of the same shape
   const size_t nquads = size_t((int64_t(B) * M * (M - 1) / 2 + 1) / 2);
   if (e->quad_B != B || e->quad_M != M || !e->quads) {
@@ -165,7 +166,7 @@ static int all_pairs_dev(Engine* e, const double* d_frames, int B, int M, int L,
   }
   void* qp = e->quads;
   const int64_t np = int64_t(B) * M * (M - 1) / 2;
-  return e->pair_correlations(*pl, spectra, rows, static_cast<const int4*>(qp), np, L, *prm, d_table, nullptr, d_corr);
+  return e->pair_correlations(*pl, spectra, rows, static_cast<const int4*>(qp), np, L, *prm, d_table, nullptr, d_corr, nonzero);
 }
 
 // explicit pair list over R equal-length rows (host buffers): one-vs-many bootstrap batches, sparse pair sets
@@ -186,15 +187,16 @@ static int pairs_host(Engine* e, const double* rows_in, int R, int L, const int3
   PAL_TRY(e->get_plan(2 * L - 1, L, 2 * L - 1, &pl));
   void *df = nullptr, *sp = nullptr, *dt = nullptr, *dq = nullptr;
   PAL_TRY(e->scratch(4, size_t(R) * L * sizeof(double), &df));
-  PAL_TRY(e->scratch(2, size_t(R) * pl->spec_stride() * sizeof(cd), &sp));
+  PAL_TRY(e->scratch(2, size_t(R) * pl->spec_stride() * sizeof(cd) + size_t(R) * sizeof(int), &sp));
+  int* nonzero = reinterpret_cast<int*>(static_cast<cd*>(sp) + size_t(R) * pl->spec_stride());
   PAL_TRY(e->scratch(5, size_t(P) * sizeof(pal_pair_record), &dt));
   PAL_TRY(e->scratch(3, quads.size() * sizeof(int4), &dq));
   PAL_TRY(e->check(hipMemcpyAsync(df, rows_in, size_t(R) * L * sizeof(double), hipMemcpyHostToDevice, e->stream), "rows upload"));
   PAL_TRY(e->check(hipMemcpyAsync(dq, quads.data(), quads.size() * sizeof(int4), hipMemcpyHostToDevice, e->stream), "pairs upload"));
   PAL_TRY(e->check(hipStreamSynchronize(e->stream), "upload sync"));
-  PAL_TRY(e->forward_spectra(*pl, static_cast<const double*>(df), size_t(L), R, L, static_cast<cd*>(sp)));
+  PAL_TRY(e->forward_spectra(*pl, static_cast<const double*>(df), size_t(L), R, L, static_cast<cd*>(sp), nonzero));
   PAL_TRY(e->pair_correlations(*pl, static_cast<const cd*>(sp), R, static_cast<const int4*>(dq), P, L, *prm,
-                               static_cast<pal_pair_record*>(dt), nullptr, nullptr));
+                               static_cast<pal_pair_record*>(dt), nullptr, nullptr, nonzero));
   return e->check(hipMemcpyAsync(table, dt, size_t(P) * sizeof(pal_pair_record), hipMemcpyDeviceToHost, e->stream), "table download");
 }
 
@@ -244,6 +246,8 @@ int pal_create(int device, pal_handle* out) {
   if (env) e->allow_pfa = atoi(env) != 0;
   env = getenv("PAL_RADER");
   if (env) e->allow_rader = atoi(env) != 0;
+  env = getenv("PAL_FUSED");
+  if (env) e->fuse_peaks = atoi(env) != 0;
   env = getenv("PAL_PFA_SUB");
   if (env) e->pfa_sub = atoi(env);
   *out = reinterpret_cast<pal_handle>(e);

@@ -1,0 +1,67 @@
+// peak_types.h - what the peak-selection launches (peaks.hip) share with the column pass that feeds them
+// directly (pfa_cols_stats.h): per-row parameters, per-segment partial results, the launch arguments.
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+namespace pal {
+
+constexpr int kList = 16384;      // capacity of a row's bracket list in global memory (doubles)
+
+struct RowPre {                          // pivot launch -> the other two
+  double k0, ka;                         // ~ mean(x), ~ mean(|x|): shifts of the one-pass sums
+  double lo, hi;                         // pivots around the median of |x| (0 / inf when no median is needed)
+  double vfloor, pfloor;                 // fused column pass: lower bounds of the row's maximum and of its highest strict
+                                         // peak, taken from the block sample (-inf: none); samples below cannot be either
+};
+
+struct Partial {                         // one segment's share of the streaming pass
+  double vmax, vmin, hb, s1, s2, a1, a2;
+  double plat;                           // fused column pass only: highest sample with an equal neighbour (-inf: none)
+  long long below;
+  int imax, imin, mb, pad;
+};
+
+struct PeakArgs {
+  const double* corr;
+  size_t stride;
+  int n, n2;
+  double fs, mult, med;   // med: NaN = no window
+  int method, dist, num_peaks, snr_w;   // method: 0 median, 1 adaptive, < 0 metrics only
+  int splits, tiles_per_seg;             // segments per row, tiles per segment
+  int edge_n2;                           // > 0: segments are column blocks of the prime-factor grid (row length edge_n2);
+                                         //      the finish launch tests the samples of columns 0 and edge_n2 - 1 itself
+  RowPre* pre;                           // [rows]
+  Partial* parts;                        // [rows][splits]
+  double* glist;                         // [rows][kList] bracket values
+  int* gcount;                           // [rows] fill of glist (> kList: overflow, the finish kernel re-reads the row)
+  unsigned long long* stamps;            // diagnostics (PAL_DEBUG_STAMPS=1): [rows][8] 100 MHz clock reads of the finish launch
+};
+
+__device__ __forceinline__ bool higher(double h1, int m1, double h2, int m2) {   // priority(h1,m1) > priority(h2,m2)
+  return h1 > h2 || (h1 == h2 && m1 > m2);
+}
+
+// one row's parameters through the scalar cache (uniform address, written by the previous launch)
+__device__ __forceinline__ RowPre load_pre(const RowPre* pre, int row) {
+  const auto* p = reinterpret_cast<const __attribute__((address_space(4))) double*>(reinterpret_cast<uintptr_t>(pre)) + 6 * size_t(row);
+  RowPre r;
+  r.k0 = p[0]; r.ka = p[1]; r.lo = p[2]; r.hi = p[3]; r.vfloor = p[4]; r.pfloor = p[5];
+  return r;
+}
+
+// neighbour lanes through DPP wave shifts (one VALU move per dword, no LDS crossbar)
+__device__ __forceinline__ double from_lower_lane(double v) {   // lane i receives lane i - 1 (lane 0: zero, never used)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x138, 0xf, 0xf, true);           // wave_shr:1
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_upper_lane(double v) {   // lane i receives lane i + 1 (lane 63: zero, never used)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x130, 0xf, 0xf, true);           // wave_shl:1
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+}  // namespace pal

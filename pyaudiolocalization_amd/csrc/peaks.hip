@@ -38,6 +38,8 @@
 #include <vector>
 
 #include "engine.h"
+#include "peak_types.h"
+#include "pfa_sample.h"
 #include "reduce.h"
 
 namespace pal {
@@ -48,7 +50,6 @@ constexpr int kT = 512;           // lanes of the pivot and finish kernels (one 
 constexpr int kNW = kT / 64;
 constexpr int kTS = 256;          // lanes of the stream kernel (one segment per workgroup)
 constexpr int kNWS = kTS / 64;
-constexpr int kList = 16384;      // capacity of a row's bracket list in global memory (doubles)
 constexpr int kLoc = 3072;        // LDS capacity of one segment's share of it (a segment of 11 tiles brackets ~1100 values)
 constexpr int kMaxTilesPerSeg = 11;
 constexpr int kSample = 8192;     // block sample that places the pivots
@@ -58,31 +59,6 @@ constexpr int kMemo = 1024;       // resolved peaks remembered per selection
 constexpr int kStack = 64;        // depth of the suppression recursion
 constexpr int kUnroll = 4;        // 16-byte loads in flight per lane
 constexpr int kTile = kTS * kUnroll;   // element pairs per tile of the stream
-
-struct RowPre {                          // k_peak_pivots -> the other two
-  double k0, ka;                         // ~ mean(x), ~ mean(|x|): shifts of the one-pass sums
-  double lo, hi;                         // pivots around the median of |x| (0 / inf when no median is needed)
-};
-
-struct Partial {                         // one segment's share of the streaming pass
-  double vmax, vmin, hb, s1, s2, a1, a2;
-  long long below;
-  int imax, imin, mb, pad;
-};
-
-struct PeakArgs {
-  const double* corr;
-  size_t stride;
-  int n, n2;
-  double fs, mult, med;   // med: NaN = no window
-  int method, dist, num_peaks, snr_w;   // method: 0 median, 1 adaptive, < 0 metrics only
-  int splits, tiles_per_seg;             // segments per row, tiles per segment
-  RowPre* pre;                           // [rows]
-  Partial* parts;                        // [rows][splits]
-  double* glist;                         // [rows][kList] bracket values
-  int* gcount;                           // [rows] fill of glist (> kList: overflow, the finish kernel re-reads the row)
-  unsigned long long* stamps;            // diagnostics (PAL_DEBUG_STAMPS=1): [rows][8] 100 MHz clock reads of the finish launch
-};
 
 struct Shared {                          // pivot and finish kernels
   unsigned hist[kBins];
@@ -112,10 +88,6 @@ struct StreamShared {                    // stream kernel
   int count;
   int bc_i;
 };
-
-__device__ __forceinline__ bool higher(double h1, int m1, double h2, int m2) {   // priority(h1,m1) > priority(h2,m2)
-  return h1 > h2 || (h1 == h2 && m1 > m2);
-}
 
 __device__ double bsum(double v, Shared& s, int tid) { return block_sum<kNW>(v, s.red_d, tid); }
 template <int N, int NW> __device__ void bsum_many(double (&v)[N], double* many, int tid) {   // N sums, one barrier pair
@@ -476,20 +448,6 @@ struct Stream {            // per-lane accumulators of the single pass over a se
   int below;
 };
 
-// neighbour lanes through DPP wave shifts (one VALU move per dword, no LDS crossbar)
-__device__ __forceinline__ double from_lower_lane(double v) {   // lane i receives lane i - 1 (lane 0: zero, never used)
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_mov_dpp(lo, 0x138, 0xf, 0xf, true);           // wave_shr:1 (no `old` operand: no copy in front)
-  hi = __builtin_amdgcn_mov_dpp(hi, 0x138, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double from_upper_lane(double v) {   // lane i receives lane i + 1 (lane 63: zero, never used)
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_mov_dpp(lo, 0x130, 0xf, 0xf, true);           // wave_shl:1
-  hi = __builtin_amdgcn_mov_dpp(hi, 0x130, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-
 // statistics of one sample: selects instead of branches (the loop is issue-bound, and a divergent branch costs
 // more scalar bookkeeping than the handful of conditional moves it would skip).  First occurrence wins inside a
 // lane because the lane meets its samples in increasing index order.  vmax / vmin / hb start at -inf / +inf / -inf.
@@ -534,34 +492,18 @@ __device__ __forceinline__ void peak_test(Stream& t, const double* c, int n, int
   if (peak_fast(t, i - lane_off, i >= 1 && i <= n - 2, l, x, r)) peak_plateau(t, c, n, i, x, lane_off);
 }
 
-// one row's parameters through the scalar cache (uniform address, written by the previous launch)
-__device__ __forceinline__ RowPre load_pre(const RowPre* pre, int row) {
-  const auto* p = reinterpret_cast<const __attribute__((address_space(4))) double*>(reinterpret_cast<uintptr_t>(pre)) + 4 * size_t(row);
-  RowPre r;
-  r.k0 = p[0]; r.ka = p[1]; r.lo = p[2]; r.hi = p[3];
-  return r;
-}
-
 // ------------------------------------------------------------------ 1. pivots
-// block sample (16 coalesced runs of 512 samples spread over the row): shifts for the one-pass variances and
-// the pivots that bracket the median
-__global__ __launch_bounds__(kT) void k_peak_pivots(PeakArgs a) {
-  __shared__ Shared s;
-  const int tid = threadIdx.x;
-  const int row = blockIdx.x;
-  const double* c = a.corr + size_t(row) * a.stride;
+// a block sample of the row gives the shifts of the one-pass variances and the pivots that bracket the median.
+// RUNS values per lane, `ns` of them real in the whole workgroup (the others are zero and `have` of this lane's
+// values are real, the first ones).
+template <int RUNS> __device__ __forceinline__ void pivot_search(const PeakArgs& a, Shared& s, int tid, int row, const double* sv,
+                                                                  const bool* real, int ns, double vfloor = -INFINITY,
+                                                                  double pfloor = -INFINITY) {
   const int n = a.n;
-  if (tid == 0) a.gcount[row] = 0;      // the row's bracket list starts empty (the stream launch behind this one fills it)
-  constexpr int kRuns = kSample / kT;
-  const int ns = n < kSample ? n : kSample;
-  double sv[kRuns];
   double ssum = 0, sabs = 0;
 #pragma unroll
-  for (int q = 0; q < kRuns; ++q) {
-    const int si = tid + q * kT;
-    const size_t at = n <= kSample ? size_t(si) : size_t((long long)q * (n - kT) / (kRuns - 1)) + tid;
-    sv[q] = si < ns ? c[at] : 0.0;
-    ssum += sv[q];
+  for (int q = 0; q < RUNS; ++q) {
+    ssum += sv[q];                                             // (values that are not real are zero)
     sabs += fabs(sv[q]);
   }
   double both[2] = {ssum, sabs};
@@ -576,8 +518,8 @@ __global__ __launch_bounds__(kT) void k_peak_pivots(PeakArgs a) {
     const double top = ka > 0 ? 4.0 * ka : 1.0;               // median <= 2 mean for non-negative data
     const double inv = double(kBins - 1) / top;
 #pragma unroll
-    for (int q = 0; q < kRuns; ++q) {
-      if (tid + q * kT < ns) {
+    for (int q = 0; q < RUNS; ++q) {
+      if (real[q]) {
         int b = int(fabs(sv[q]) * inv);
         atomicAdd(&s.hist[b < kBins - 1 ? b : kBins - 1], 1u);
       }
@@ -600,8 +542,67 @@ __global__ __launch_bounds__(kT) void k_peak_pivots(PeakArgs a) {
   if (tid == 0) {
     RowPre pre;
     pre.k0 = k0; pre.ka = ka; pre.lo = lo; pre.hi = hi;
+    pre.vfloor = vfloor; pre.pfloor = pfloor;
     a.pre[row] = pre;
+    a.gcount[row] = 0;      // the row's bracket list starts empty (the launch behind this one fills it)
   }
+}
+
+// sample = 16 coalesced runs of 512 values spread over the row
+__global__ __launch_bounds__(kT) void k_peak_pivots(PeakArgs a) {
+  __shared__ Shared s;
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x;
+  const double* c = a.corr + size_t(row) * a.stride;
+  const int n = a.n;
+  constexpr int kRuns = kSample / kT;
+  const int ns = n < kSample ? n : kSample;
+  double sv[kRuns];
+  bool real[kRuns];
+#pragma unroll
+  for (int q = 0; q < kRuns; ++q) {
+    const int si = tid + q * kT;
+    const size_t at = n <= kSample ? size_t(si) : size_t((long long)q * (n - kT) / (kRuns - 1)) + tid;
+    real[q] = si < ns;
+    sv[q] = real[q] ? c[at] : 0.0;
+  }
+  pivot_search<kRuns>(a, s, tid, row, sv, real, ns);
+}
+
+// the same for a row that does not exist yet: sample values computed from the prime-factor grid (pfa_sample.h)
+template <int TC> __global__ __launch_bounds__(kT) void k_peak_pivots_grid(PeakArgs a, PfaSample sp) {
+  __shared__ Shared s;
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x;
+  double sv[2 * TC];
+  pfa_sample_row<TC>(sp, row, tid, sv);
+  bool real[2 * TC];
+  const int ch = tid >> 7, h = (sp.N1 - 1) / 2;
+  int per_col = 0;                                            // values per sampled column over the four chunks (uniform)
+  for (int c4 = 0; c4 < 4; ++c4)
+    for (int tt = 0; tt < TC; ++tt) per_col += (c4 < sp.nch && c4 * TC + tt + 1 <= h) ? 2 : 0;
+#pragma unroll
+  for (int tt = 0; tt < TC; ++tt) real[tt] = real[TC + tt] = ch < sp.nch && ch * TC + tt + 1 <= h;
+  // Lower bounds for the column pass: the sample's maximum, and its highest strict peak (the clusters of 8 neighbouring
+  // columns give the six inner lanes of a cluster both neighbours m -/+ 1 of the same output index).  The values are the
+  // row's own (same operations in the same order as the column pass); a relative 1e-9 of slack anyway, and the finish
+  // launch rescans a row whose best peak ends up below the bound.
+  const int within = tid & 7;
+  double vm = -INFINITY, pm = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < 2 * TC; ++q) {
+    const double x = sv[q];
+    const double left = from_lower_lane(x), right = from_upper_lane(x);
+    vm = real[q] ? fmax(vm, x) : vm;
+    pm = real[q] && within >= 1 && within <= 6 && left < x && right < x ? fmax(pm, x) : pm;
+  }
+  vm = block_max<kNW>(vm, s.red_d, tid);
+  __syncthreads();
+  pm = block_max<kNW>(pm, s.red_d, tid);
+  __syncthreads();
+  vm -= fabs(vm) * 1e-9;
+  pm -= fabs(pm) * 1e-9;
+  pivot_search<2 * TC>(a, s, tid, row, sv, real, per_col * kSampleCols, vm, pm);
 }
 
 // ------------------------------------------------------------------ 2. stream
@@ -762,6 +763,7 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
     Partial pt;
     pt.vmax = vmax; pt.vmin = vmin; pt.hb = hb; pt.s1 = sums[0]; pt.s2 = sums[1]; pt.a1 = sums[2]; pt.a2 = sums[3];
     pt.below = (long long)sums[4]; pt.imax = imax; pt.imin = imin; pt.mb = mb; pt.pad = 0;
+    pt.plat = -INFINITY;
     a.parts[size_t(row) * S + seg] = pt;
   }
 }
@@ -789,8 +791,10 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   int imax = -1, imin = -1, mb = -1;
   double vmax = 0, vmin = 0, hb = 0, s1 = 0, s2 = 0, a1 = 0, a2 = 0;
   long long below = 0;
+  double plat = -INFINITY;
   for (int q = 0; q < S; ++q) {
     const Partial pt = a.parts[size_t(row) * S + q];
+    plat = fmax(plat, pt.plat);
     if (pt.imax >= 0 && (imax < 0 || arg_better<0>(pt.vmax, pt.imax, vmax, imax))) { vmax = pt.vmax; imax = pt.imax; }
     if (pt.imin >= 0 && (imin < 0 || arg_better<1>(pt.vmin, pt.imin, vmin, imin))) { vmin = pt.vmin; imin = pt.imin; }
     if (pt.mb >= 0 && (mb < 0 || higher(pt.hb, pt.mb, hb, mb))) { hb = pt.hb; mb = pt.mb; }
@@ -801,8 +805,55 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   const int cnt = want_median ? a.gcount[row] : 0;
   const double* list = a.glist + size_t(row) * kList;
   const double mean_abs = ka + a1 / double(n);                 // np.mean(np.abs(corr)) (utils.py:155)
+  if (a.edge_n2 > 0 && imax < 0) {                             // no sample reached the pivot launch's bound for the maximum: scan
+    double bv = 0;
+    int bi = -1;
+    for (int i = tid; i < n; i += kT) {
+      const double x = c[i];
+      if (x == x && (bi < 0 || x > bv)) { bv = x; bi = i; }
+    }
+    barg<0>(bv, bi, s, tid);
+    if (bi >= 0) { vmax = bv; imax = bi; }
+  }
   if (imax < 0 || imax >= n) imax = 0;                         // all-NaN row (and a guard for every index used below)
   if (mb >= n) mb = -1;
+  if (a.edge_n2 > 0) {
+    // The segments were column blocks of the prime-factor grid (pfa_cols_stats.h): the samples of the grid's first
+    // and last column (neighbours in another output row) had no peak test there, and samples with an equal neighbour
+    // were only reported (`plat`).  Strict peaks and plateau STARTS are tested here (a start walks to its plateau's
+    // end once; a start that is not in an edge column has been reported).
+    const int N2 = a.edge_n2, N1 = n / N2;
+    double tie = -INFINITY;                                    // highest edge-column sample with an equal neighbour
+    auto test = [&](int m, double& bh, int& bm) {
+      if (m < 1 || m > n - 2) return;
+      const double xl = c[m - 1], x = c[m], xr = c[m + 1];
+      if (xl == x || xr == x) tie = fmax(tie, x);
+      int at = -1;
+      if (xl < x && xr < x) at = m;
+      else if (xl < x && xr == x) {
+        int q = m + 1;
+        while (q < n - 1 && c[q] == x) ++q;
+        if (c[q] < x) at = (m + q - 1) / 2;
+      }
+      if (at >= 0 && (bm < 0 || higher(x, at, bh, bm))) { bh = x; bm = at; }
+    };
+    double eh = 0;
+    int em = -1;
+    for (int k = tid; k < 2 * N1; k += kT) test(k < N1 ? N2 * k : N2 * (k - N1) + N2 - 1, eh, em);
+    barg<2>(eh, em, s, tid);
+    if (em >= 0 && (mb < 0 || higher(eh, em, hb, mb))) { hb = eh; mb = em; }
+    plat = fmax(plat, block_max<kNW>(tie, s.red_d, tid));
+    // (the column pass only tested samples above the pivot launch's bounds: a best peak below the bound means the bound
+    //  was not one - rescan)
+    if ((plat > -INFINITY && (mb < 0 || plat >= hb)) || (pre.pfloor > -INFINITY && (mb < 0 || hb < pre.pfloor))) {          // a plateau may outrank the best strict peak: rescan the row
+      eh = 0;
+      em = -1;
+      for (int m = 1 + tid; m <= n - 2; m += kT) test(m, eh, em);
+      barg<2>(eh, em, s, tid);
+      hb = eh;
+      mb = em;
+    }
+  }
 
   // ---- SNR (utils.py:238-250): totals minus the window around the maximum ----
   const int wlo_s = imax - a.snr_w > 0 ? imax - a.snr_w : 0;
@@ -930,31 +981,34 @@ static int* g_status_dev(Engine* e) {
   return static_cast<int*>(p);
 }
 
-int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, const pal_phat_params& prm,
-                  pal_pair_record* table, int32_t* ksel_multi, hipStream_t on) {
-  if (rows <= 0) return PAL_OK;
+int Engine::peaks_setup(const double* corr, size_t stride, int rows, int n, int n2, const pal_phat_params& prm, int blocks, int grid_n2,
+                        hipStream_t on, PeakArgs& a) {
   const bool metrics_only = prm.threshold_method < 0;
   if (!metrics_only) {
     if (prm.num_peaks < 1 || prm.num_peaks > PAL_MAX_PEAKS) return fail(PAL_ERR_INVALID, "num_peaks %d outside 1..%d", prm.num_peaks, PAL_MAX_PEAKS);
     if (prm.peak_distance < 1) return fail(PAL_ERR_INVALID, "`distance` must be greater or equal to 1");
   }
   if (n < 1) return fail(PAL_ERR_INVALID, "empty correlation");
-  int* status = g_status_dev(this);
-  if (!status) return fail(PAL_ERR_NOMEM, "status word");
-  PeakArgs a;
   a.corr = corr; a.stride = stride; a.n = n; a.n2 = n2;
   a.fs = prm.fs; a.mult = prm.threshold_multiplier; a.med = prm.max_expected_delay;
   a.method = prm.threshold_method; a.dist = prm.peak_distance; a.num_peaks = prm.num_peaks;
   const int w = int(0.01 * double(n));                       // utils.py:244
   a.snr_w = w > 1 ? w : 1;
-  // segments: about 1024 workgroups per launch (four resident per CU, all in flight at once), so that a workgroup
-  // streams as many tiles as possible behind one set of fixed costs (row parameters, reductions, publish)
-  const int ntiles = ((n + 1) / 2 + kTile - 1) / kTile;
-  int want = 1024 / rows;                                     // (rounded down: one resident round rather than a second, short one)
-  want = want < 1 ? 1 : (want > ntiles ? ntiles : want);
-  a.tiles_per_seg = (ntiles + want - 1) / want;
-  if (a.tiles_per_seg > kMaxTilesPerSeg) a.tiles_per_seg = kMaxTilesPerSeg;   // the segment's bracket values must fit its LDS list
-  a.splits = (ntiles + a.tiles_per_seg - 1) / a.tiles_per_seg;
+  a.edge_n2 = blocks > 0 ? grid_n2 : 0;
+  a.stamps = nullptr;
+  if (blocks > 0) {
+    a.splits = blocks;
+    a.tiles_per_seg = 0;
+  } else {
+    // segments: about 1024 workgroups per launch (four resident per CU, all in flight at once), so that a workgroup
+    // streams as many tiles as possible behind one set of fixed costs (row parameters, reductions, publish)
+    const int ntiles = ((n + 1) / 2 + kTile - 1) / kTile;
+    int want = 1024 / rows;                                     // (rounded down: one resident round rather than a second, short one)
+    want = want < 1 ? 1 : (want > ntiles ? ntiles : want);
+    a.tiles_per_seg = (ntiles + want - 1) / want;
+    if (a.tiles_per_seg > kMaxTilesPerSeg) a.tiles_per_seg = kMaxTilesPerSeg;   // the segment's bracket values must fit its LDS list
+    a.splits = (ntiles + a.tiles_per_seg - 1) / a.tiles_per_seg;
+  }
   // per-stream scratch: [gcount | pre | parts | glist]; the pivot launch zeroes the list fills
   size_t off_pre = (size_t(rows) * sizeof(int) + 127) & ~size_t(127);
   size_t off_parts = (off_pre + size_t(rows) * sizeof(RowPre) + 127) & ~size_t(127);
@@ -967,16 +1021,19 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
   a.pre = reinterpret_cast<RowPre*>(base + off_pre);
   a.parts = reinterpret_cast<Partial*>(base + off_parts);
   a.glist = reinterpret_cast<double*>(base + off_list);
-  {
-    ProfScope ps(this, "k_peak_pivots", on);
-    k_peak_pivots<<<dim3(rows), dim3(kT), 0, on>>>(a);
-    PAL_HIP(hipGetLastError());
-  }
-  {
-    ProfScope ps(this, "k_peak_stream", on);
-    k_peak_stream<<<dim3(unsigned(rows) * unsigned(a.splits)), dim3(kTS), 0, on>>>(a);
-    PAL_HIP(hipGetLastError());
-  }
+  return PAL_OK;
+}
+
+int Engine::peaks_pivots_grid(const PeakArgs& a, int rows, const PfaSample& sp, hipStream_t on) {
+  ProfScope ps(this, "k_peak_pivots_grid", on);
+  k_peak_pivots_grid<kPfaTC><<<dim3(rows), dim3(kT), 0, on>>>(a, sp);
+  return check(hipGetLastError(), "k_peak_pivots_grid");
+}
+
+int Engine::peaks_finish(PeakArgs& a, int rows, pal_pair_record* table, int32_t* ksel_multi, hipStream_t on) {
+  const bool metrics_only = a.method < 0;
+  int* status = g_status_dev(this);
+  if (!status) return fail(PAL_ERR_NOMEM, "status word");
   a.stamps = nullptr;
   static const bool want_stamps = getenv("PAL_DEBUG_STAMPS") != nullptr;
   if (want_stamps) {
@@ -1002,6 +1059,24 @@ int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, co
     }
   }
   return PAL_OK;
+}
+
+int Engine::peaks(const double* corr, size_t stride, int rows, int n, int n2, const pal_phat_params& prm,
+                  pal_pair_record* table, int32_t* ksel_multi, hipStream_t on) {
+  if (rows <= 0) return PAL_OK;
+  PeakArgs a;
+  PAL_TRY(peaks_setup(corr, stride, rows, n, n2, prm, 0, 0, on, a));
+  {
+    ProfScope ps(this, "k_peak_pivots", on);
+    k_peak_pivots<<<dim3(rows), dim3(kT), 0, on>>>(a);
+    PAL_HIP(hipGetLastError());
+  }
+  {
+    ProfScope ps(this, "k_peak_stream", on);
+    k_peak_stream<<<dim3(unsigned(rows) * unsigned(a.splits)), dim3(kTS), 0, on>>>(a);
+    PAL_HIP(hipGetLastError());
+  }
+  return peaks_finish(a, rows, table, ksel_multi, on);
 }
 
 }  // namespace pal

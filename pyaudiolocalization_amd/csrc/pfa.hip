@@ -27,6 +27,7 @@
 
 #include "pfa_kernels.h"
 #include "pfa_rader.h"
+#include "pfa_cols_stats.h"
 
 namespace pal {
 
@@ -215,8 +216,7 @@ int Engine::build_rader(Pfa& f, long long n, long long u2) {
   return PAL_OK;
 }
 
-int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, double* corr, size_t stride,
-                           hipStream_t on) {
+int Engine::pfa_rows(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, hipStream_t on) {
   const Pfa& f = pl.pfa;
   const cd* tws = f.lm >= 11 ? stage_table_compact(f.lm) : stage_table(f.lm);
   if (f.rader) {
@@ -234,14 +234,48 @@ int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads
     PAL_SWITCH_LM(f.lm, k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, on>>>(a));
     PAL_HIP(hipGetLastError());
   }
+  return PAL_OK;
+}
+
+int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, double* corr, size_t stride,
+                           const int* zero_rows, hipStream_t on) {
+  const Pfa& f = pl.pfa;
+  PAL_TRY(pfa_rows(pl, permuted, quads, G, Y, on));
   {
     ProfScope ps(this, "k_pfa_cols", on);
     const unsigned nblk = unsigned(f.n2 + 63) / 64;
     k_pfa_cols<kPfaTC, kPfaUnr><<<dim3(unsigned(G) * nblk, unsigned(f.nch + 3) / 4), dim3(256), 0, on>>>(Y, corr, stride, f.n1,
-                                                                                                     f.n2, G, f.nch, f.T);
+                                                                                                     f.n2, G, f.nch, f.T, zero_rows);
     PAL_HIP(hipGetLastError());
   }
   return PAL_OK;
+}
+
+// the fused column pass applies when one workgroup covers every output index (nch <= 4) and the grid is large
+// enough for the block sample of the pivots (pfa_sample.h: 128 columns x 64 or more output indices)
+bool Engine::pfa_can_fuse(const Plan& pl) const {
+  const Pfa& f = pl.pfa;
+  return fuse_peaks && f.on() && f.nch >= 3 && f.nch <= 4 && f.n2 >= 128;
+}
+
+// row pass, pivots from the grid, column pass + streaming statistics, finish: the peak selection of one launch
+// group without the separate read of its correlation rows (pfa_cols_stats.h)
+int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, double* corr, size_t stride,
+                                 const int* zero_rows, const pal_phat_params& prm, int n2, pal_pair_record* table, int32_t* ksel_multi,
+                                 hipStream_t on) {
+  const Pfa& f = pl.pfa;
+  const int nblk = (f.n2 + kColsOwn - 1) / kColsOwn;
+  PeakArgs a;
+  PAL_TRY(peaks_setup(corr, stride, rows, pl.n, n2, prm, nblk, f.n2, on, a));
+  PAL_TRY(pfa_rows(pl, permuted, quads, G, Y, on));
+  const PfaSample sp{Y, f.T, zero_rows, f.n1, f.n2, f.nch};
+  PAL_TRY(peaks_pivots_grid(a, rows, sp, on));
+  {
+    ProfScope ps(this, "k_pfa_cols_stats", on);
+    k_pfa_cols_stats<kPfaTC, kPfaUnr><<<dim3(unsigned(G) * unsigned(nblk)), dim3(256), 0, on>>>(Y, corr, stride, f.n1, f.n2, G, f.nch, f.T, zero_rows, a, rows);
+    PAL_HIP(hipGetLastError());
+  }
+  return peaks_finish(a, rows, table, ksel_multi, on);
 }
 
 }  // namespace pal

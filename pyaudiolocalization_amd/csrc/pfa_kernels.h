@@ -2,11 +2,10 @@
 // tools/microbench_pfa.hip can time the same kernels with ablated functors.
 #pragma once
 #include "conv_kernels.h"
+#include "pfa_sample.h"   // kPfaTC, kPfaUnr
 
 namespace pal {
 
-constexpr int kPfaTC = 11;   // output indices t per wavefront of the column pass (x 4 accumulators each)
-constexpr int kPfaUnr = 4;   // steps j per loop iteration of the column pass (the table is padded with kPfaUnr zero rows)
 
 // ------------------------------------------------------------------ functors of the chirp-spectrum setup kernel
 template <int LM> struct PfaChirpIn {     // chirp kernel of the convolution: h[d mod M] = conj(b[|d|]), |d| < N2
@@ -273,24 +272,18 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
 //   q:  c[t] = Im Y_0 + sum_j cos(j t) Im E_j + sum_j sin(j t) Re O_j,   c[N1-t] = the same with - sin
 // T[(j-1)][chunk][cos | sin][tt] is wave-uniform: scalar loads, SGPR operands of v_fmac_f64.  The pass is bound by
 // memory latency, not arithmetic: kPfaUnr steps share one batch of loads, issued one batch ahead of its FMAs.
+// the accumulation of one lane's column: cx/sy (pair p) and cy/sx (pair q) for the TC indices of chunk `ch`, the
+// plain sums for t = 0.  Steps beyond h meet zero rows of the table; the next batch of loads is issued ahead.
 template <int TC, int UNR>
-__global__ __launch_bounds__(256) void k_pfa_cols(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
-                                                  int N1, int N2, int G, int nch, const double* __restrict__ T) {
-  const int lane = threadIdx.x & 63;
-  const int ch = int(blockIdx.y) * 4 + __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
-  if (ch >= nch) return;
-  const int g = blockIdx.x % G, cb = blockIdx.x / G;
-  const int m2 = cb * 64 + lane;
-  const bool live = m2 < N2;
-  const cd* Yg = Y + size_t(g) * N1 * N2 + (live ? m2 : N2 - 1);
+__device__ __forceinline__ void pfa_cols_accumulate(const cd* __restrict__ Yg, int N1, int N2, int nch, int ch, const double* __restrict__ T,
+                                                    cd& y0, double* cx, double* sy, double* cy, double* sx, double& sumx, double& sumy) {
   const int h = (N1 - 1) / 2;
-  double cx[TC], sy[TC], cy[TC], sx[TC];
 #pragma unroll
   for (int tt = 0; tt < TC; ++tt) cx[tt] = sy[tt] = cy[tt] = sx[tt] = 0.0;
-  double sumx = 0.0, sumy = 0.0;
+  sumx = sumy = 0.0;
   const double* Tj = T + size_t(ch) * 2 * TC;
   const size_t tstep = size_t(nch) * 2 * TC;
-  const cd y0 = Yg[0];
+  y0 = Yg[0];
   cd yj[UNR], ym[UNR];
 #pragma unroll
   for (int u = 0; u < UNR; ++u) {
@@ -324,9 +317,36 @@ __global__ __launch_bounds__(256) void k_pfa_cols(const cd* __restrict__ Y, doub
 #pragma unroll
     for (int u = 0; u < UNR; ++u) { yj[u] = nj[u]; ym[u] = nm[u]; }
   }
+}
+
+template <int TC, int UNR>
+__global__ __launch_bounds__(256) void k_pfa_cols(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
+                                                  int N1, int N2, int G, int nch, const double* __restrict__ T,
+                                                  const int* __restrict__ zero_rows) {
+  const int lane = threadIdx.x & 63;
+  const int ch = int(blockIdx.y) * 4 + __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+  if (ch >= nch) return;
+  const int g = blockIdx.x % G, cb = blockIdx.x / G;
+  const int m2 = cb * 64 + lane;
+  const bool live = m2 < N2;
+  const cd* Yg = Y + size_t(g) * N1 * N2 + (live ? m2 : N2 - 1);
+  const int h = (N1 - 1) / 2;
+  double cx[TC], sy[TC], cy[TC], sx[TC];
+  double sumx, sumy;
+  cd y0;
+  pfa_cols_accumulate<TC, UNR>(Yg, N1, N2, nch, ch, T, y0, cx, sy, cy, sx, sumx, sumy);
   if (!live) return;
   double* outp = corr + size_t(2 * g) * stride + m2;
   double* outq = outp + stride;
+  // a pair with a silent microphone has R = 0 in every bin: its row is exactly zero in the reference, while the packed
+  // transform leaves the other pair's rounding noise (1e-17) in it
+  const double kp = zero_rows && zero_rows[2 * g] ? 0.0 : 1.0, kq = zero_rows && zero_rows[2 * g + 1] ? 0.0 : 1.0;
+  if (kp == 0.0) { y0.x = sumx = 0.0; }
+  if (kq == 0.0) { y0.y = sumy = 0.0; }
+#pragma unroll
+  for (int tt = 0; tt < TC; ++tt) {
+    cx[tt] *= kp; sy[tt] *= kp; cy[tt] *= kq; sx[tt] *= kq;
+  }
   if (ch == 0) { outp[0] = y0.x + sumx; outq[0] = y0.y + sumy; }
 #pragma unroll
   for (int tt = 0; tt < TC; ++tt) {

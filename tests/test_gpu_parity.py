@@ -79,6 +79,7 @@ def test_prime_factor_route_odd_pair_counts_and_tables(engine, monkeypatch):
         for mics, length, fs, med in ((5, 3000, 16000.0, 0.004), (3, 2048, 8000.0, None), (6, 500, 8000.0, None)):
             frames = rng.standard_normal((2, mics, length))
             frames[:, 1:] += 0.6 * frames[:, :1]
+            frames[1, mics - 1] = 0.0          # a silent microphone: its pairs' rows are exactly zero in the reference
             t1, c1 = engine.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, want_corr=True)
             t0, c0 = plain.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, want_corr=True)
             assert np.max(np.abs(c1 - c0)) <= 1e-13
@@ -88,10 +89,77 @@ def test_prime_factor_route_odd_pair_counts_and_tables(engine, monkeypatch):
                 want = O.all_pairs(frames[b], fs, max_expected_delay=med)
                 for name in ("k_sel", "branch", "k_argmax"):
                     assert np.array_equal(t1[b][name], want[name]), name        # bit-exact integer outputs
+                    assert np.array_equal(t0[b][name], want[name]), name
                 assert np.allclose(t1[b]["cmax"], want["cmax"], rtol=1e-11, atol=0)
                 assert np.allclose(t1[b]["snr"], want["snr"], rtol=1e-9, atol=0)
     finally:
         plain.close()
+
+
+# frame lengths whose split has 47 <= N1 <= 89 and N2 >= 128: there the column pass of the prime-factor route also does
+# the streaming pass of the peak selection (pfa_cols_stats.h); PAL_FUSED=0 keeps the separate launches
+FUSED_LENGTHS = [(11962, 47, 509), (15525, 61, 509), (22651, 89, 509)]
+
+
+@pytest.mark.parametrize("length,n1,n2", FUSED_LENGTHS)
+@pytest.mark.parametrize("method", ["median", "adaptive"])
+def test_fused_column_pass_matches_separate_launches_and_oracle(engine, length, n1, n2, method, monkeypatch):
+    from pyaudiolocalization_amd import Engine
+    info = engine.plan_info(length)
+    assert (info["n1"], info["n2"]) == (n1, n2), info
+    rng = np.random.default_rng(length)
+    frames = rng.standard_normal((2, 5, length))                # 10 pairs = 5 packed transforms per frame
+    frames[:, 1:] += 0.5 * frames[:, :1]
+    frames[1, 3] = 0.0                                          # a silent microphone: four all-zero correlation rows (plateaus)
+    fs, med = 16000.0, 0.02
+    engine.profile_begin()
+    t1, c1 = engine.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, threshold_method=method, want_corr=True)
+    engine.profile_end()
+    ent = engine.profile_entries()
+    assert ent["k_pfa_cols_stats"][1] >= 1 and ent["k_peak_pivots_grid"][1] >= 1 and "k_peak_stream" not in ent, ent
+    monkeypatch.setenv("PAL_FUSED", "0")
+    plain = Engine(engine.device)
+    try:
+        plain.profile_begin()
+        t0, c0 = plain.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, threshold_method=method, want_corr=True)
+        plain.profile_end()
+        assert "k_pfa_cols_stats" not in plain.profile_entries()
+    finally:
+        plain.close()
+    assert np.array_equal(c1, c0)                               # the same FMAs in the same order
+    for name in ("k_sel", "branch", "k_argmax", "n_sel", "cmax", "cmin", "sel_height"):
+        assert np.array_equal(t1[name], t0[name]), name
+    assert np.allclose(t1["snr"], t0["snr"], rtol=1e-12, atol=0)   # the shifted sums are added in another order
+    for b in range(2):
+        want = O.all_pairs(frames[b], fs, max_expected_delay=med, threshold_method=method)
+        for name in ("k_sel", "branch", "k_argmax"):
+            assert np.array_equal(t1[b][name], want[name]), name
+        assert np.allclose(t1[b]["snr"], want["snr"], rtol=1e-9, atol=0)
+
+
+def test_fused_column_pass_plateaus_and_grid_edges(engine, monkeypatch):
+    """Samples with equal neighbours and peaks in the grid's first / last column (lags m = 0 or N2 - 1 mod N2) take the
+    finish launch's own tests: quantised inputs give exact ties, and the window is the whole row."""
+    from pyaudiolocalization_amd import Engine
+    length = 11962
+    rng = np.random.default_rng(5)
+    frames = np.round(rng.standard_normal((3, 3, length)) * 2) / 2     # 3 pairs: the second packed transform is half empty
+    frames[:, 1] = np.roll(frames[:, 0], 509, axis=-1)          # true lag = a multiple of N2 = 509: column 0 of the grid
+    frames[:, 2] = np.roll(frames[:, 0], -508, axis=-1)         # column N2 - 1, one output index lower
+    t1 = engine.gcc_phat_all_pairs(frames, 8000.0)
+    monkeypatch.setenv("PAL_FUSED", "0")
+    plain = Engine(engine.device)
+    try:
+        t0 = plain.gcc_phat_all_pairs(frames, 8000.0)
+    finally:
+        plain.close()
+    for name in ("k_sel", "branch", "k_argmax", "n_sel", "cmax", "cmin", "sel_height"):
+        assert np.array_equal(t1[name], t0[name]), name
+    for b in range(3):
+        want = O.all_pairs(frames[b], 8000.0)
+        for name in ("k_sel", "branch", "k_argmax"):
+            assert np.array_equal(t1[b][name], want[name]), name
+
 
 
 def test_phat_of_identical_and_silent_signals(engine):

@@ -370,6 +370,7 @@ int main(int argc, char** argv) {
     for (unsigned w = 0; w < grid; ++w) { t0 = std::min(t0, hs[size_t(w) * 8]); t1 = std::max(t1, hs[size_t(w) * 8 + 4]); }
     printf("  rows launch span %.1f us\n", double(t1 - t0) / 100.0);
   }
+  PfaRaderArgs ra_keep{};
   {   // Rader row pass: random but valid tables (timing only)
     constexpr int LR = 990;
     int *qidx, *ridx;
@@ -388,6 +389,7 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&st, sizeof(unsigned long long) * 8 * grid));
     PfaRaderArgs ra{SP, quad, Y, bhat, r1, t2f, t2i, t3f, t3i, ridx, rowtab, N1, N2, NR, G, 1.0f / float(N1), 1.0 / double(n), nullptr};
     time_it("rows (Rader 11 x 9 x 10): product", 20, [&] { k_pfa_rows_rader<11, 9, 10><<<dim3(grid), dim3(256)>>>(ra); });
+    ra_keep = ra;
     ra.stamps = st;
     k_pfa_rows_rader<11, 9, 10><<<dim3(grid), dim3(256)>>>(ra);
     CHECK(hipDeviceSynchronize());
@@ -455,6 +457,22 @@ int main(int argc, char** argv) {
       const char* nm[4] = {"cols, cols on one stream", "cols || cols on two streams", "rows, rows on one stream", "rows || rows on two streams"};
       printf("  %-44s %8.1f us per iteration (wall)\n", nm[mode - 3], us);
     }
+    for (int pad : {0, 18, 45})     // Rader rows with dynamic LDS padding (4 / 3 / 2 workgroups per CU) beside the column pass
+      for (int mode = 0; mode < 3; ++mode) {
+        if (mode == 1 && pad) continue;
+        PfaRaderArgs r2 = ra_keep;
+        r2.Y = Y2;
+        CHECK(hipDeviceSynchronize());
+        auto t0 = std::chrono::steady_clock::now();
+        const int reps = 20;
+        for (int i = 0; i < reps; ++i) {
+          if (mode != 1) k_pfa_rows_rader<11, 9, 10><<<dim3(grid), dim3(256), size_t(pad) * 1024, sa>>>(r2);
+          if (mode != 0) k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, mode == 2 ? sb : sa>>>(Y, corr, stride, N1, N2, G, 4, T);
+        }
+        CHECK(hipDeviceSynchronize());
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+        printf("  rader pad %2d KB: %-30s %8.1f us per iteration (wall)\n", pad, mode == 0 ? "rows alone" : mode == 1 ? "cols alone" : "rows || cols on two streams", us);
+      }
     for (int mode = 0; mode < 3; ++mode) {
       CHECK(hipDeviceSynchronize());
       auto t0 = std::chrono::steady_clock::now();
