@@ -151,7 +151,8 @@ struct Engine {
   int pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, double* corr, size_t stride,
                            const int* zero_rows, const pal_phat_params& prm, int n2, pal_pair_record* table, int32_t* ksel_multi,
                            hipStream_t on);
-  bool fuse_peaks = true;     // PAL_FUSED=0: separate column pass and peak stream even where the fused launch applies
+  bool fuse_peaks = false;    // PAL_FUSED=1: column pass + peak statistics in one launch where it applies (pfa_cols_stats.h;
+                              // measured break-even at 44.1 kHz x 1 s: the pivots then cost a pass over the grid)
 };
 
 struct ProfScope {

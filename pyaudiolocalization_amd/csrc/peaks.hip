@@ -574,8 +574,9 @@ template <int TC> __global__ __launch_bounds__(kT) void k_peak_pivots_grid(PeakA
   __shared__ Shared s;
   const int tid = threadIdx.x;
   const int row = blockIdx.x;
+  __shared__ double tab[kSampleTabMax];
   double sv[2 * TC];
-  pfa_sample_row<TC>(sp, row, tid, sv);
+  pfa_sample_row<TC>(sp, row, tid, tab, sv);
   bool real[2 * TC];
   const int ch = tid >> 7, h = (sp.N1 - 1) / 2;
   int per_col = 0;                                            // values per sampled column over the four chunks (uniform)

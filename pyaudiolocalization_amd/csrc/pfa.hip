@@ -255,7 +255,7 @@ int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads
 // enough for the block sample of the pivots (pfa_sample.h: 128 columns x 64 or more output indices)
 bool Engine::pfa_can_fuse(const Plan& pl) const {
   const Pfa& f = pl.pfa;
-  return fuse_peaks && f.on() && f.nch >= 3 && f.nch <= 4 && f.n2 >= 128;
+  return fuse_peaks && f.on() && f.nch >= 3 && f.nch <= 4 && f.n1 <= 89 && f.n2 >= 128;
 }
 
 // row pass, pivots from the grid, column pass + streaming statistics, finish: the peak selection of one launch

@@ -18,9 +18,13 @@ struct PfaSample {
 
 constexpr int kSampleCols = 128;   // columns per row sample; x 4 chunks x 2 TC values = lanes x values per lane
 
+constexpr int kSampleTabMax = 44 * 4 * 2 * kPfaTC;   // table doubles of the largest grid the fused column pass takes (h <= 44, nch <= 4)
+
 // lane `tid` of a 512-lane workgroup: chunk ch = tid / 128 (wave-uniform), column from tid % 128.
-// out[tt] = c[t], out[TC + tt] = c[N1 - t] for t = ch TC + tt + 1; returns how many of the 2 TC values exist.
-template <int TC> __device__ __forceinline__ int pfa_sample_row(const PfaSample& sp, int row, int tid, double* out) {
+// out[tt] = c[t], out[TC + tt] = c[N1 - t] for t = ch TC + tt + 1 (zero where t > h).
+// `tab` (LDS, kSampleTabMax doubles) receives the cos / sin rows first: with one workgroup per CU the table (31 KB at
+// N1 = 89) does not stay in the scalar cache, and a scalar load per step that goes to L2 made this loop 20 us long.
+template <int TC> __device__ __forceinline__ void pfa_sample_row(const PfaSample& sp, int row, int tid, double* tab, double* out) {
   const int g = row >> 1, part = row & 1;
   const int N1 = sp.N1, N2 = sp.N2, h = (N1 - 1) / 2;
   const int ch = __builtin_amdgcn_readfirstlane(tid >> 7), ci = tid & (kSampleCols - 1);
@@ -28,24 +32,35 @@ template <int TC> __device__ __forceinline__ int pfa_sample_row(const PfaSample&
   int m2 = int((long long)cluster * (N2 - 8) / 15) + within;
   m2 = m2 < 0 ? 0 : (m2 > N2 - 1 ? N2 - 1 : m2);
   const cd* Yg = sp.Y + size_t(g) * N1 * N2 + m2;
+  const int tstep = sp.nch * 2 * TC;
+  for (int k = tid; k < h * tstep; k += 512) tab[k] = sp.T[k];
   double ca[TC], sb[TC];
 #pragma unroll
   for (int tt = 0; tt < TC; ++tt) ca[tt] = sb[tt] = 0.0;
   const cd y0 = Yg[0];
-  const size_t tstep = size_t(sp.nch) * 2 * TC;
-  const auto* Tj = reinterpret_cast<const __attribute__((address_space(4))) double*>(reinterpret_cast<uintptr_t>(sp.T)) + size_t(ch) * 2 * TC;
   const bool chunk_ok = ch < sp.nch;
-  if (chunk_ok) {
-    for (int j = 1; j <= h; j += 4) {
-      cd yj[4], ym[4];
+  constexpr int U = 4;                                         // steps per batch, the next batch's loads in flight (as in the column pass)
+  cd yj[U], ym[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int jj = j + u <= h ? j + u : h;
-        yj[u] = Yg[size_t(jj) * N2];
-        ym[u] = Yg[size_t(N1 - jj) * N2];
+  for (int u = 0; u < U; ++u) {
+    const int jj = 1 + u <= h ? 1 + u : h;
+    yj[u] = Yg[size_t(jj) * N2];
+    ym[u] = Yg[size_t(h > 0 ? N1 - jj : 0) * N2];
+  }
+  __syncthreads();
+  if (chunk_ok) {
+    const double* Tj = tab + ch * 2 * TC;
+    for (int j = 1; j <= h; j += U) {
+      cd nj[U], nm[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jn = j + U + u <= h ? j + U + u : h;
+        nj[u] = Yg[size_t(jn) * N2];
+        nm[u] = Yg[size_t(N1 - jn) * N2];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u, Tj += tstep) {               // steps beyond h meet zero rows of the table
+      for (int u = 0; u < U; ++u, Tj += tstep) {
+        if (j + u > h) continue;                               // (uniform; the LDS copy has no zero rows behind step h)
         // pair p (real parts): cos (y_j.x + y_-j.x) -/+ sin (y_j.y - y_-j.y);  pair q: cos (y_j.y + y_-j.y) +/- sin (y_j.x - y_-j.x)
         const double a = part ? yj[u].y + ym[u].y : yj[u].x + ym[u].x;
         const double b = part ? yj[u].x - ym[u].x : yj[u].y - ym[u].y;
@@ -55,20 +70,19 @@ template <int TC> __device__ __forceinline__ int pfa_sample_row(const PfaSample&
           sb[tt] = __builtin_fma(Tj[TC + tt], b, sb[tt]);
         }
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { yj[u] = nj[u]; ym[u] = nm[u]; }
     }
   }
   const double base = part ? y0.y : y0.x;
   const bool zero = sp.zero_rows && sp.zero_rows[row];
-  int have = 0;
 #pragma unroll
   for (int tt = 0; tt < TC; ++tt) {
     const bool ok = chunk_ok && ch * TC + tt + 1 <= h;
     const double d = part ? -sb[tt] : sb[tt];
     out[tt] = ok && !zero ? base + ca[tt] - d : 0.0;
     out[TC + tt] = ok && !zero ? base + ca[tt] + d : 0.0;
-    have += ok ? 2 : 0;
   }
-  return have;
 }
 
 }  // namespace pal

@@ -97,7 +97,7 @@ def test_prime_factor_route_odd_pair_counts_and_tables(engine, monkeypatch):
 
 
 # frame lengths whose split has 47 <= N1 <= 89 and N2 >= 128: there the column pass of the prime-factor route also does
-# the streaming pass of the peak selection (pfa_cols_stats.h); PAL_FUSED=0 keeps the separate launches
+# the streaming pass of the peak selection when PAL_FUSED=1 asks for it (pfa_cols_stats.h; off by default)
 FUSED_LENGTHS = [(11962, 47, 509), (15525, 61, 509), (22651, 89, 509)]
 
 
@@ -113,19 +113,19 @@ def test_fused_column_pass_matches_separate_launches_and_oracle(engine, length, 
     frames[1, 3] = 0.0                                          # a silent microphone: four all-zero correlation rows (plateaus)
     fs, med = 16000.0, 0.02
     engine.profile_begin()
-    t1, c1 = engine.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, threshold_method=method, want_corr=True)
+    t0, c0 = engine.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, threshold_method=method, want_corr=True)
     engine.profile_end()
-    ent = engine.profile_entries()
-    assert ent["k_pfa_cols_stats"][1] >= 1 and ent["k_peak_pivots_grid"][1] >= 1 and "k_peak_stream" not in ent, ent
-    monkeypatch.setenv("PAL_FUSED", "0")
-    plain = Engine(engine.device)
+    assert "k_pfa_cols_stats" not in engine.profile_entries()
+    monkeypatch.setenv("PAL_FUSED", "1")
+    fused = Engine(engine.device)
     try:
-        plain.profile_begin()
-        t0, c0 = plain.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, threshold_method=method, want_corr=True)
-        plain.profile_end()
-        assert "k_pfa_cols_stats" not in plain.profile_entries()
+        fused.profile_begin()
+        t1, c1 = fused.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, threshold_method=method, want_corr=True)
+        fused.profile_end()
+        ent = fused.profile_entries()
+        assert ent["k_pfa_cols_stats"][1] >= 1 and ent["k_peak_pivots_grid"][1] >= 1 and "k_peak_stream" not in ent, ent
     finally:
-        plain.close()
+        fused.close()
     assert np.array_equal(c1, c0)                               # the same FMAs in the same order
     for name in ("k_sel", "branch", "k_argmax", "n_sel", "cmax", "cmin", "sel_height"):
         assert np.array_equal(t1[name], t0[name]), name
@@ -146,13 +146,13 @@ def test_fused_column_pass_plateaus_and_grid_edges(engine, monkeypatch):
     frames = np.round(rng.standard_normal((3, 3, length)) * 2) / 2     # 3 pairs: the second packed transform is half empty
     frames[:, 1] = np.roll(frames[:, 0], 509, axis=-1)          # true lag = a multiple of N2 = 509: column 0 of the grid
     frames[:, 2] = np.roll(frames[:, 0], -508, axis=-1)         # column N2 - 1, one output index lower
-    t1 = engine.gcc_phat_all_pairs(frames, 8000.0)
-    monkeypatch.setenv("PAL_FUSED", "0")
-    plain = Engine(engine.device)
+    t0 = engine.gcc_phat_all_pairs(frames, 8000.0)
+    monkeypatch.setenv("PAL_FUSED", "1")
+    fused = Engine(engine.device)
     try:
-        t0 = plain.gcc_phat_all_pairs(frames, 8000.0)
+        t1 = fused.gcc_phat_all_pairs(frames, 8000.0)
     finally:
-        plain.close()
+        fused.close()
     for name in ("k_sel", "branch", "k_argmax", "n_sel", "cmax", "cmin", "sel_height"):
         assert np.array_equal(t1[name], t0[name]), name
     for b in range(3):
