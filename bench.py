@@ -203,8 +203,11 @@ def main() -> None:
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"metric run: {b} frame(s)/step/GPU x {m} mics x {length} samples @ {FS} Hz, "
                                    f"{pairs} pairs/frame, max_expected_delay={med}, exact DFT length n={info['n']}"
-                                   + (f" = {info['n1']} x {info['n2']} (prime-factor inverse: in-LDS chirp convolutions of "
-                                      f"{info['tile_len']} points + dense column DFTs; forward spectra via chirp convolution "
+                                   + (f" = {info['n1']} x {info['n2']} (prime-factor inverse: "
+                                      + (f"Rader row DFTs, cyclic convolutions of {info['n2'] - 1} points in LDS"
+                                         if info['tile_len'] & (info['tile_len'] - 1) else
+                                         f"in-LDS chirp convolutions of {info['tile_len']} points")
+                                      + f" + dense column DFTs; forward spectra via chirp convolution "
                                       f"{info['m1']}x{info['m2']})" if info.get("n1") else
                                       f" via chirp convolution {info['m1']}x{info['m2']}"),
                        "frames_per_step_per_gpu": b, "mics": m, "samples": length, "pairs_per_frame": pairs,

@@ -165,8 +165,9 @@ int pal_profile_entry(pal_handle h, int index, char* name, int cap, double* tota
 int pal_plan_info(pal_handle h, int L, int32_t* n, int32_t* conv_len, int32_t* m1, int32_t* m2);
 
 /* Prime-factor route of the inverse transform for frame length L: n = n1 * n2 (coprime, odd) with the n2-point
- * DFTs as in-LDS chirp convolutions of `tile_len` points.  All three are 0 when n has no such split (or
- * PAL_PFA=0) and the four-step chirp convolution reported by pal_plan_info does the inverse too. */
+ * DFTs as in-LDS convolutions of `tile_len` points: a chirp convolution (tile_len a power of two >= 2 n2 - 1) or,
+ * for n2 = 991, Rader's cyclic convolution (tile_len = n2 - 1 = 990).  All three are 0 when n has no such split
+ * (or PAL_PFA=0) and the four-step chirp convolution reported by pal_plan_info does the inverse too. */
 int pal_plan_factors(pal_handle h, int L, int32_t* n1, int32_t* n2, int32_t* tile_len);
 
 #ifdef __cplusplus

@@ -442,7 +442,7 @@ int pal_plan_factors(pal_handle h, int L, int32_t* n1, int32_t* n2, int32_t* til
   PAL_TRY(e->get_plan(2 * L - 1, L, 2 * L - 1, &pl));
   if (n1) *n1 = pl->pfa.n1;
   if (n2) *n2 = pl->pfa.n2;
-  if (tile_len) *tile_len = pl->pfa.on() ? 1 << pl->pfa.lm : 0;
+  if (tile_len) *tile_len = pl->pfa.on() ? (pl->pfa.rader ? pl->pfa.n2 - 1 : 1 << pl->pfa.lm) : 0;
   return PAL_OK;
 }
 

@@ -38,8 +38,8 @@ def test_phat_correlation_matches_numpy(engine, n1, n2):
 # frame lengths whose n = 2L-1 exercises every shape of the prime-factor route (pfa.hip): one row tile
 # (99 = 1 x 99, 999 = 1 x 999; 991 = 1 x 991 and 88199 = 89 x 991 take the Rader row pass of pfa_rader.h), dense column DFTs with N1 = 9 / 7 / 3 / 11 / 89, tiles of 1024 / 2048 / 4096 points,
 # and lengths that have no usable split (1999 prime) and stay on the four-step chirp convolution
-PFA_LENGTHS = [(50, 1, 99, 1024), (496, 1, 991, 2048), (500, 1, 999, 2048), (1000, 0, 0, 0), (2048, 9, 455, 1024), (2999, 3, 1999, 4096),
-               (3000, 7, 857, 2048), (5000, 11, 909, 2048), (44100, 89, 991, 2048)]
+PFA_LENGTHS = [(50, 1, 99, 1024), (496, 1, 991, 990), (500, 1, 999, 2048), (1000, 0, 0, 0), (2048, 9, 455, 1024), (2999, 3, 1999, 4096),
+               (3000, 7, 857, 2048), (5000, 11, 909, 2048), (44100, 89, 991, 990)]
 
 
 @pytest.mark.parametrize("length,n1,n2,tile", PFA_LENGTHS)
@@ -66,6 +66,30 @@ def test_prime_factor_route_matches_four_step_and_numpy(engine, length, n1, n2, 
     assert np.max(np.abs(got - want)) <= 1e-12 * scale          # fp64 rounding of a length-n transform: ~1e-14
     assert np.max(np.abs(ref - want)) <= 1e-12 * scale
     assert int(np.argmax(got)) == int(np.argmax(want)) == int(np.argmax(ref))
+
+
+def test_rader_rows_match_chirp_convolution_rows(engine, monkeypatch):
+    """n2 = 991: the Rader row pass (pfa_rader.h) against the chirp-convolution tile (PAL_RADER=0) on the same plan."""
+    from pyaudiolocalization_amd import Engine
+    assert engine.plan_info(496)["tile_len"] == 990
+    rng = np.random.default_rng(991)
+    frames = rng.standard_normal((2, 5, 496))
+    frames[:, 1:] += 0.5 * frames[:, :1]
+    t1, c1 = engine.gcc_phat_all_pairs(frames, 16000.0, max_expected_delay=0.01, want_corr=True)
+    monkeypatch.setenv("PAL_RADER", "0")
+    plain = Engine(engine.device)
+    try:
+        assert plain.plan_info(496)["tile_len"] == 2048
+        t0, c0 = plain.gcc_phat_all_pairs(frames, 16000.0, max_expected_delay=0.01, want_corr=True)
+    finally:
+        plain.close()
+    assert np.max(np.abs(c1 - c0)) <= 1e-13
+    for name in ("k_sel", "branch", "k_argmax", "n_sel"):
+        assert np.array_equal(t1[name], t0[name]), name
+    for b in range(2):
+        want = O.all_pairs(frames[b], 16000.0, max_expected_delay=0.01)
+        for name in ("k_sel", "branch", "k_argmax"):
+            assert np.array_equal(t1[b][name], want[name]), name
 
 
 def test_prime_factor_route_odd_pair_counts_and_tables(engine, monkeypatch):

@@ -14,7 +14,8 @@ cases = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 bad = ties = rows = 0
 t0 = time.time()
 for case in range(cases):
-    L = int(rng.choice([rng.integers(2, 64), rng.integers(64, 700), rng.integers(700, 3000), rng.integers(3000, 9000)]))
+    L = int(rng.choice([rng.integers(2, 64), rng.integers(64, 700), rng.integers(700, 3000), rng.integers(3000, 9000),
+                        rng.choice([496, 11962, 15525, 22651, 44100])]))   # (Rader rows at 991 = 2 x 496 - 1, fused column pass with PAL_FUSED=1)
     mics = int(rng.integers(2, 7))
     fs = float(rng.choice([8000.0, 16000.0, 44100.0, 48000.0]))
     med = None if rng.random() < 0.4 else float(rng.choice([0.0005, 0.002, 0.01, 0.05]))
@@ -31,6 +32,8 @@ for case in range(cases):
         frames = np.stack([np.sin(2 * np.pi * 440 * (t + d / fs)) for d in rng.integers(0, 20, mics)]) + 1e-3 * rng.standard_normal((mics, L))
     else:                                           # sparse / partly silent
         frames = rng.standard_normal((mics, L)) * (rng.random((mics, L)) < 0.05)
+    if rng.random() < 0.15:                         # a silent microphone: exactly zero rows in the reference
+        frames[int(rng.integers(0, mics))] = 0.0
     if int(fs * 0.001) < 1:
         continue
     try:
