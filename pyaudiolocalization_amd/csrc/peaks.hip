@@ -202,34 +202,46 @@ __device__ __forceinline__ bool peak_mid(const double* c, int n, int m, double& 
 // returns false when that bin is too crowded for the exact search (caller falls back to the radix select)
 __device__ bool list_select(Shared& s, int tid, const double* __restrict__ list, int cnt, unsigned rank, double lo, double hi,
                             double& out) {
+  constexpr int kKeep = 16;                                    // list values a lane keeps in registers between the two passes
   for (int k = tid; k < kBins; k += kT) s.hist[k] = 0;
   if (tid == 0) s.count2 = 0;
   __syncthreads();
   const double span = hi - lo;
   const double inv = (span > 0 && isfinite(span)) ? double(kBins - 1) / span : 0.0;
-  for (int e = tid; e < cnt; e += kT) {
-    int b = int((list[e] - lo) * inv);
-    b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
-    atomicAdd(&s.hist[b], 1u);
+  auto bin_of = [&](double v) {
+    int b = int((v - lo) * inv);
+    return b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+  };
+  double keep[kKeep];
+#pragma unroll
+  for (int q = 0; q < kKeep; ++q) {                            // all loads in flight together
+    const int e = tid + q * kT;
+    keep[q] = e < cnt ? list[e] : 0.0;
   }
+#pragma unroll
+  for (int q = 0; q < kKeep; ++q)
+    if (tid + q * kT < cnt) atomicAdd(&s.hist[bin_of(keep[q])], 1u);
+  for (int e = tid + kKeep * kT; e < cnt; e += kT) atomicAdd(&s.hist[bin_of(list[e])], 1u);
   __syncthreads();
   unsigned bin, inner, pop;
   find_bin(s, tid, rank, bin, inner, pop);
   if (pop == 0 || pop > unsigned(kSmall)) return false;
-  for (int e0 = 0; e0 < cnt; e0 += kT) {
-    const int e = e0 + tid;
-    bool hit = false;
-    double v = 0;
-    if (e < cnt) {
-      v = list[e];
-      int b = int((v - lo) * inv);
-      b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
-      hit = unsigned(b) == bin;
+  // the winning bin holds a handful of values: a lane that owns one takes a slot with its own LDS atomic
+#pragma unroll
+  for (int q = 0; q < kKeep; ++q)
+    if (tid + q * kT < cnt && unsigned(bin_of(keep[q])) == bin) {
+      const int at = atomicAdd(&s.count2, 1);
+      if (at < kSmall) s.small[at] = keep[q];
     }
-    append(hit, v, s.small, &s.count2, kSmall, tid & 63);
+  for (int e = tid + kKeep * kT; e < cnt; e += kT) {
+    const double v = list[e];
+    if (unsigned(bin_of(v)) == bin) {
+      const int at = atomicAdd(&s.count2, 1);
+      if (at < kSmall) s.small[at] = v;
+    }
   }
   __syncthreads();
-  const int m = s.count2;
+  const int m = s.count2 < kSmall ? s.count2 : kSmall;
   for (int e = tid; e < m; e += kT) {
     const double v = s.small[e];
     unsigned below = 0;
