@@ -154,7 +154,7 @@ def main() -> None:
     b_alg = algorithmic_bytes_per_pair(m, length)
     # pairs one launch of the pair pipeline processes: a step is cut into launch groups of `chunk` packed transforms
     # (two pairs each); the events sample every args.event_every-th group, so the launch COUNT says nothing here
-    chunk = args.chunk if args.chunk > 0 else int(os.environ.get("PAL_CHUNK", "128"))
+    chunk = eng.pair_group_size(length)
     groups_per_step = -(-((b * pairs + 1) // 2) // chunk)
     pairs_per_launch = b * pairs / groups_per_step
     roofline = None

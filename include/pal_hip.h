@@ -76,8 +76,11 @@ int pal_create(int device, pal_handle* out);
 void pal_destroy(pal_handle h);
 const char* pal_last_error(pal_handle h); /* h may be NULL: error of the last failed pal_create */
 int pal_synchronize(pal_handle h);
-/* transforms processed per launch group (workspace = chunk * M * 16 B); 0 keeps the default */
+/* transforms processed per launch group (workspace = chunk * M * 16 B); 0 keeps the default: 128, and for the pair
+ * pipeline (two pairs per transform) 256 where one workspace slot stays below 1 GiB, 32 at least */
 int pal_set_chunk(pal_handle h, int chunk);
+/* packed transforms (pairs / 2) one launch group of the all-pairs pipeline carries for frames of L samples */
+int pal_pair_group_size(pal_handle h, int L, int32_t* transforms);
 
 /* ---- device buffers (so that a host language needs no HIP binding of its own) ---------- */
 int pal_device_alloc(pal_handle h, size_t bytes, void** dptr);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "pal_last_error": (C.c_char_p, [_H]),
     "pal_synchronize": (C.c_int, [_H]),
     "pal_set_chunk": (C.c_int, [_H, C.c_int]),
+    "pal_pair_group_size": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int32)]),
     "pal_device_alloc": (C.c_int, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
     "pal_device_free": (C.c_int, [_H, C.c_void_p]),
     "pal_upload": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -331,6 +331,7 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
   const Conv& c = pl.inv;
   const int n = pl.n;
   const bool pfa = pl.pfa.on();
+  const int chunk = pair_group(n);   // (shadows the engine-wide group size: larger groups amortise launch tails and the peak kernels' fixed costs)
   const cd* permuted = spectra;   // forward_spectra wrote the (k mod N1, k mod N2) layout when the plan has the split
   (void)nspec;
   // Launch groups alternate between two HIP streams, each with its own workspace and correlation buffer: the

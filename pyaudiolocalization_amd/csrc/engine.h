@@ -88,7 +88,13 @@ struct Engine {
   bool allow_rader = true;         // PAL_RADER=0 keeps the row pass on the in-LDS chirp convolution
   int pfa_sub = 0;                 // transforms per row/column pass of the prime-factor route (PAL_PFA_SUB; 0 = whole group)
   std::string err;
-  int chunk = 128;                              // transforms per launch group (256 PHAT rows per peak-kernel launch: one per CU)
+  int chunk = 128;                              // transforms per launch group (forward spectra, simulation, synchronisation)
+  bool chunk_auto = true;                       // pair pipeline: 256 transforms per group where a workspace slot stays <= 1 GiB
+  int pair_group(int n) const {                 // (PAL_CHUNK / pal_set_chunk fix both)
+    if (!chunk_auto) return chunk;
+    const long long g = (1ll << 30) / (16ll * (n > 0 ? n : 1));
+    return int(g < 32 ? 32 : (g > 256 ? 256 : g));
+  }
   std::map<std::tuple<int, int, int>, Plan> plans;   // (n, lin, nout) -> plan
   cd* stage_tw[13] = {};                        // stage-major twiddles per log2 N
   cd* stage_twc[13] = {};                       // the same with a compact last stage (fft_core.h stage_twc_size)

@@ -237,7 +237,7 @@ int pal_create(int device, pal_handle* out) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->cu_count = cus;
   }
   const char* env = getenv("PAL_CHUNK");
-  if (env && atoi(env) > 0) e->chunk = atoi(env);
+  if (env && atoi(env) > 0) { e->chunk = atoi(env); e->chunk_auto = false; }
   env = getenv("PAL_OVERLAP");
   if (env) e->overlap = atoi(env);
   env = getenv("PAL_RADIX3");
@@ -299,7 +299,7 @@ int pal_synchronize(pal_handle h) {
 int pal_set_chunk(pal_handle h, int chunk) {
   ENGINE(h);
   if (chunk < 0 || chunk > 4096) return e->fail(PAL_ERR_INVALID, "chunk %d outside 0..4096", chunk);
-  if (chunk > 0) e->chunk = chunk;
+  if (chunk > 0) { e->chunk = chunk; e->chunk_auto = false; }
   return PAL_OK;
 }
 
@@ -432,6 +432,13 @@ int pal_plan_info(pal_handle h, int L, int32_t* n, int32_t* conv_len, int32_t* m
   if (conv_len) *conv_len = int32_t(pl->inv.M());
   if (m1) *m1 = pl->inv.M1();
   if (m2) *m2 = pl->inv.M2();
+  return PAL_OK;
+}
+
+int pal_pair_group_size(pal_handle h, int L, int32_t* transforms) {
+  ENGINE(h);
+  if (L < 1) return e->fail(PAL_ERR_INVALID, "frame length %d", L);
+  if (transforms) *transforms = e->pair_group(2 * L - 1);
   return PAL_OK;
 }
 

@@ -83,6 +83,12 @@ class Engine:
     def set_chunk(self, chunk: int) -> None:
         self._check(self._lib.pal_set_chunk(self._h, int(chunk)))
 
+    def pair_group_size(self, length: int) -> int:
+        """Packed transforms (two pairs each) per launch group of the all-pairs pipeline for frames of `length` samples."""
+        g = C.c_int32()
+        self._check(self._lib.pal_pair_group_size(self._h, int(length), C.byref(g)))
+        return g.value
+
     def alloc(self, nbytes: int) -> int:
         p = C.c_void_p()
         self._check(self._lib.pal_device_alloc(self._h, int(nbytes), C.byref(p)))
