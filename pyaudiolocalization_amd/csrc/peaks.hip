@@ -80,11 +80,14 @@ struct Shared {                          // pivot and finish kernels
   int bc_i[4];
 };
 
+struct StreamWave {                      // one wavefront's share of a segment's statistics
+  double vmax, vmin, hb, sums[5];
+  int imax, mb;
+};
+
 struct StreamShared {                    // stream kernel
   double list[kLoc + 1];                 // + one dump slot for the unconditional stores of values outside the bracket
-  double red_d[kNWS];
-  double many[kNWS * 8];
-  int red_i[kNWS];
+  StreamWave wave[kNWS];
   int count;
   int bc_i;
 };
@@ -463,13 +466,13 @@ struct Stream {            // per-lane accumulators of the single pass over a se
 // statistics of one sample: selects instead of branches (the loop is issue-bound, and a divergent branch costs
 // more scalar bookkeeping than the handful of conditional moves it would skip).  First occurrence wins inside a
 // lane because the lane meets its samples in increasing index order.  vmax / vmin / hb start at -inf / +inf / -inf.
-template <bool FULL> __device__ __forceinline__ void visit(Stream& t, double x, int i, bool valid, double k0, double ka) {
+template <bool FULL> __device__ __forceinline__ void visit_max(Stream& t, double x, int i, bool valid) {
   const bool up = (FULL || valid) && x > t.vmax;
   t.imax = up ? i : t.imax;
   t.vmax = up ? x : t.vmax;
-  const bool dn = (FULL || valid) && x < t.vmin;
-  t.imin = dn ? i : t.imin;
-  t.vmin = dn ? x : t.vmin;
+}
+template <bool FULL> __device__ __forceinline__ void visit(Stream& t, double x, bool valid, double k0, double ka) {
+  t.vmin = (FULL || valid) ? fmin(t.vmin, x) : t.vmin;
   const double d = (FULL || valid) ? x - k0 : 0.0, e = (FULL || valid) ? fabs(x) - ka : 0.0;
   t.s1 += d;
   t.s2 = __builtin_fma(d, d, t.s2);
@@ -578,7 +581,24 @@ __global__ __launch_bounds__(kT) void k_peak_pivots(PeakArgs a) {
     real[q] = si < ns;
     sv[q] = real[q] ? c[at] : 0.0;
   }
-  pivot_search<kRuns>(a, s, tid, row, sv, real, ns);
+  // Lower bounds for the stream launch: the sample's maximum, and its highest strict peak (inside a run the lanes
+  // tid -/+ 1 of the same wavefront hold the neighbours).  A sample below them can be neither the row's maximum nor its
+  // highest local maximum, which lets the stream keep the index bookkeeping and the neighbour tests out of its loop.
+  const int lane = tid & 63;
+  double vm = -INFINITY, pm = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < kRuns; ++q) {
+    const double x = sv[q];
+    const double left = from_lower_lane(x), right = from_upper_lane(x);
+    vm = real[q] ? fmax(vm, x) : vm;
+    const bool inner = real[q] && lane >= 1 && lane <= 62 && tid + 1 + q * kT < ns;
+    pm = inner && left < x && right < x ? fmax(pm, x) : pm;
+  }
+  vm = block_max<kNW>(vm, s.red_d, tid);
+  __syncthreads();
+  pm = block_max<kNW>(pm, s.red_d, tid);
+  __syncthreads();
+  pivot_search<kRuns>(a, s, tid, row, sv, real, ns, vm, pm);
 }
 
 // the same for a row that does not exist yet: sample values computed from the prime-factor grid (pfa_sample.h)
@@ -629,6 +649,7 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
   const bool want_median = a.method == 0;
   const RowPre pre = load_pre(a.pre, row);
   const double k0 = pre.k0, ka = pre.ka, lo = pre.lo, hi = pre.hi;
+  const double floor = fmin(pre.vfloor, pre.pfloor);           // (-inf when the sample held no strict peak: every tile is examined)
   if (tid == 0) s.count = 0;
   __syncthreads();
 
@@ -653,25 +674,32 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
   // whole tile are appended with ONE LDS atomic per wavefront: per element a ballot gives the lane's rank
   // (mbcnt) and the wavefront's count (scalar popcount), the running scalar total is the tile's reservation.
   const bool not0 = lane != 0, not63 = lane != 63;
+  // the edge elements e = 128 q and e = 128 q + 127 of this segment (at most two per lane): their values are requested
+  // now and looked at behind the stream; the neighbours are only read for the few that reach the bounds
+  static_assert(kMaxTilesPerSeg * kTile * 2 / 64 <= 2 * kTS, "two edge elements per lane");
+  int edge_at[2];
+  double edge_x[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int j = tid + r * kTS;
+    const int e = 2 * p_lo + (j >> 1) * 128 + ((j & 1) ? 127 : 0);
+    const bool ok = 2 * p_lo + 64 * j < 2 * p_hi && e >= 1 && e <= n - 2 && e < 2 * p_hi;
+    edge_at[r] = ok ? e : -1;
+    edge_x[r] = ok ? c[e] : -INFINITY;
+  }
   auto consume_tile = [&](const double* xa, const double* xb, int pair0u, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;           // full tiles: every element valid, none at index 0 or n - 1
     const int pair0 = pair0u + tid;                            // pair0u: the tile's first pair (wave-uniform)
     int off[2 * kUnroll];
     int run = 0;
-    bool plateau = false;
+    unsigned long long reach = 0;                              // lanes with a sample at or above the pivot launch's bounds
 #pragma unroll
     for (int k = 0; k < kUnroll; ++k) {
       const int e0 = 2 * (pair0 + k * kTS);
-      // indices are recorded relative to the lane's own offset 2 tid: the recorded value is wave-uniform (a scalar
-      // operand of the select instead of a vector add per sample); the lane offset is added back after the loop
-      const int u0 = 2 * (pair0u + k * kTS);
       const bool va = FULL || e0 < n, vb = FULL || e0 + 1 < n;
-      const double left = from_lower_lane(xb[k]);
-      const double right = from_upper_lane(xa[k]);
-      visit<FULL>(t, xa[k], u0, va, k0, ka);
-      visit<FULL>(t, xb[k], u0 + 1, vb, k0, ka);
-      plateau |= peak_fast(t, u0, FULL ? not0 : (not0 && va && e0 >= 1 && e0 <= n - 2), left, xa[k], xb[k]);
-      plateau |= peak_fast(t, u0 + 1, FULL ? not63 : (not63 && vb && e0 + 1 <= n - 2), xa[k], xb[k], right);
+      visit<FULL>(t, xa[k], va, k0, ka);
+      visit<FULL>(t, xb[k], vb, k0, ka);
+      reach |= __ballot((va && xa[k] >= floor) || (vb && xb[k] >= floor));
       if (want_median) {
         const double ma = fabs(xa[k]), mb_ = fabs(xb[k]);
         t.below += int(va && ma < lo) + int(vb && mb_ < lo);
@@ -687,15 +715,34 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
         off[2 * k + 1] = hb_ ? rb : kLoc;
       }
     }
-    if (__ballot(plateau)) {                                   // equal neighbours somewhere in the tile: the exact, slow test
+    if (reach) {
+      // about one tile in ten holds a sample that can be the row's maximum or its highest local maximum (none below
+      // the bounds can): only there the index bookkeeping and the neighbour tests run
+      bool plateau = false;
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) {
         const int e0 = 2 * (pair0 + k * kTS);
+        // indices are recorded relative to the lane's own offset 2 tid: the recorded value is wave-uniform (a scalar
+        // operand of the select instead of a vector add per sample); the lane offset is added back after the loop
+        const int u0 = 2 * (pair0u + k * kTS);
         const bool va = FULL || e0 < n, vb = FULL || e0 + 1 < n;
         const double left = from_lower_lane(xb[k]);
-        if (va && lane != 0 && e0 >= 1 && e0 <= n - 2 && left < xa[k] && xb[k] == xa[k]) peak_plateau(t, c, n, e0, xa[k], 2 * tid);
         const double right = from_upper_lane(xa[k]);
-        if (vb && lane != 63 && e0 + 1 <= n - 2 && xa[k] < xb[k] && right == xb[k]) peak_plateau(t, c, n, e0 + 1, xb[k], 2 * tid);
+        visit_max<FULL>(t, xa[k], u0, va);
+        visit_max<FULL>(t, xb[k], u0 + 1, vb);
+        plateau |= peak_fast(t, u0, FULL ? not0 : (not0 && va && e0 >= 1 && e0 <= n - 2), left, xa[k], xb[k]);
+        plateau |= peak_fast(t, u0 + 1, FULL ? not63 : (not63 && vb && e0 + 1 <= n - 2), xa[k], xb[k], right);
+      }
+      if (__ballot(plateau)) {                                 // equal neighbours somewhere in the tile: the exact, slow test
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k) {
+          const int e0 = 2 * (pair0 + k * kTS);
+          const bool va = FULL || e0 < n, vb = FULL || e0 + 1 < n;
+          const double left = from_lower_lane(xb[k]);
+          if (va && lane != 0 && e0 >= 1 && e0 <= n - 2 && left < xa[k] && xb[k] == xa[k]) peak_plateau(t, c, n, e0, xa[k], 2 * tid);
+          const double right = from_upper_lane(xa[k]);
+          if (vb && lane != 63 && e0 + 1 <= n - 2 && xa[k] < xb[k] && right == xb[k]) peak_plateau(t, c, n, e0 + 1, xb[k], 2 * tid);
+        }
       }
     }
     if (want_median && run > 0) {                              // wavefront-uniform
@@ -750,24 +797,52 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
     }
     consume_tile(xa, xb, full, std::false_type{});
   }
-  for (int j = tid; 2 * p_lo + 64 * j < 2 * p_hi; j += kTS) {  // edge pass: e = 128 q and e = 128 q + 127
-    const int e = 2 * p_lo + (j >> 1) * 128 + ((j & 1) ? 127 : 0);
-    if (e >= 1 && e <= n - 2 && e < 2 * p_hi) peak_test(t, c, n, e, c[e - 1], c[e], c[e + 1], 2 * tid);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {                                // edge pass
+    const int e = edge_at[r];
+    if (e >= 0 && edge_x[r] >= floor) peak_test(t, c, n, e, c[e - 1], edge_x[r], c[e + 1], 2 * tid);
   }
+  // the list's reservation in the row's global list: requested now, used behind the reductions
+  __syncthreads();
+  const int cnt = s.count;
+  if (want_median && tid == 0) s.bc_i = atomicAdd(&a.gcount[row], cnt <= kLoc ? cnt : kList + 1);   // LDS overflow poisons the list
+  // ---- one reduction for everything: wavefront shuffles, one LDS hop, lane 0 merges the four wavefronts ----
   double vmax = t.vmax, vmin = t.vmin, hb = t.hb;
-  int imax = t.imax < 0 ? -1 : t.imax + 2 * tid, imin = t.imin < 0 ? -1 : t.imin + 2 * tid, mb = t.mb < 0 ? -1 : t.mb + 2 * tid;
-  block_arg<0, kNWS>(vmax, imax, s.red_d, s.red_i, tid);
-  block_arg<1, kNWS>(vmin, imin, s.red_d, s.red_i, tid);
-  block_arg<2, kNWS>(hb, mb, s.red_d, s.red_i, tid);
-  double sums[5] = {t.s1, t.s2, t.a1, t.a2, double(t.below)};   // one barrier pair for all five (counts < 2^31 are exact in fp64)
-  bsum_many<5, kNWS>(sums, s.many, tid);
+  int imax = t.imax < 0 ? -1 : t.imax + 2 * tid, mb = t.mb < 0 ? -1 : t.mb + 2 * tid;
+  double sums[5] = {t.s1, t.s2, t.a1, t.a2, double(t.below)};   // (counts < 2^31 are exact in fp64)
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_down(vmax, o, 64);
+    const int oi = __shfl_down(imax, o, 64);
+    if (oi >= 0 && (imax < 0 || arg_better<0>(ov, oi, vmax, imax))) { vmax = ov; imax = oi; }
+    const double hv = __shfl_down(hb, o, 64);
+    const int hi_ = __shfl_down(mb, o, 64);
+    if (hi_ >= 0 && (mb < 0 || arg_better<2>(hv, hi_, hb, mb))) { hb = hv; mb = hi_; }
+    vmin = fmin(vmin, __shfl_down(vmin, o, 64));
+#pragma unroll
+    for (int q = 0; q < 5; ++q) sums[q] += __shfl_down(sums[q], o, 64);
+  }
+  if (lane == 0) {
+    StreamWave& w = s.wave[tid >> 6];
+    w.vmax = vmax; w.vmin = vmin; w.hb = hb; w.imax = imax; w.mb = mb;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) w.sums[q] = sums[q];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 1; k < kNWS; ++k) {
+      const StreamWave& w = s.wave[k];
+      if (w.imax >= 0 && (imax < 0 || arg_better<0>(w.vmax, w.imax, vmax, imax))) { vmax = w.vmax; imax = w.imax; }
+      if (w.mb >= 0 && (mb < 0 || arg_better<2>(w.hb, w.mb, hb, mb))) { hb = w.hb; mb = w.mb; }
+      vmin = fmin(vmin, w.vmin);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) sums[q] += w.sums[q];
+    }
+  }
+  const int imin = vmin < INFINITY ? 0 : -1;                   // (the finish launch only asks whether the segment has a minimum)
 
   // ---- publish: the segment's bracket values join the row's list (one global atomic), its statistics its slot ----
   if (want_median) {
-    const int cnt = s.count;
-    if (tid == 0) s.bc_i = atomicAdd(&a.gcount[row], cnt <= kLoc ? cnt : kList + 1);   // LDS overflow poisons the list
-    __syncthreads();
-    const int at = s.bc_i;
+    const int at = s.bc_i;                                     // (written before the reductions' barriers)
     double* dst = a.glist + size_t(row) * kList;
     if (cnt <= kLoc && at >= 0 && at + cnt <= kList)
       for (int k = tid; k < cnt; k += kTS) dst[at + k] = s.list[k];
@@ -818,7 +893,7 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   const int cnt = want_median ? a.gcount[row] : 0;
   const double* list = a.glist + size_t(row) * kList;
   const double mean_abs = ka + a1 / double(n);                 // np.mean(np.abs(corr)) (utils.py:155)
-  if (a.edge_n2 > 0 && imax < 0) {                             // no sample reached the pivot launch's bound for the maximum: scan
+  if (imax < 0) {                                              // no sample reached the pivot launch's bound for the maximum (insurance): scan
     double bv = 0;
     int bi = -1;
     for (int i = tid; i < n; i += kT) {
@@ -830,13 +905,9 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   }
   if (imax < 0 || imax >= n) imax = 0;                         // all-NaN row (and a guard for every index used below)
   if (mb >= n) mb = -1;
-  if (a.edge_n2 > 0) {
-    // The segments were column blocks of the prime-factor grid (pfa_cols_stats.h): the samples of the grid's first
-    // and last column (neighbours in another output row) had no peak test there, and samples with an equal neighbour
-    // were only reported (`plat`).  Strict peaks and plateau STARTS are tested here (a start walks to its plateau's
-    // end once; a start that is not in an edge column has been reported).
-    const int N2 = a.edge_n2, N1 = n / N2;
-    double tie = -INFINITY;                                    // highest edge-column sample with an equal neighbour
+  {
+    // Strict peaks and plateau STARTS, tested from memory (a start walks to its plateau's end once).
+    double tie = -INFINITY;                                    // highest tested sample with an equal neighbour
     auto test = [&](int m, double& bh, int& bm) {
       if (m < 1 || m > n - 2) return;
       const double xl = c[m - 1], x = c[m], xr = c[m + 1];
@@ -852,13 +923,20 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
     };
     double eh = 0;
     int em = -1;
-    for (int k = tid; k < 2 * N1; k += kT) test(k < N1 ? N2 * k : N2 * (k - N1) + N2 - 1, eh, em);
-    barg<2>(eh, em, s, tid);
-    if (em >= 0 && (mb < 0 || higher(eh, em, hb, mb))) { hb = eh; mb = em; }
-    plat = fmax(plat, block_max<kNW>(tie, s.red_d, tid));
-    // (the column pass only tested samples above the pivot launch's bounds: a best peak below the bound means the bound
-    //  was not one - rescan)
-    if ((plat > -INFINITY && (mb < 0 || plat >= hb)) || (pre.pfloor > -INFINITY && (mb < 0 || hb < pre.pfloor))) {          // a plateau may outrank the best strict peak: rescan the row
+    if (a.edge_n2 > 0) {
+      // The segments were column blocks of the prime-factor grid (pfa_cols_stats.h): the samples of the grid's first
+      // and last column (neighbours in another output row) had no peak test there, and samples with an equal neighbour
+      // were only reported (`plat`; a plateau start that is not in an edge column has been reported).
+      const int N2 = a.edge_n2, N1 = n / N2;
+      for (int k = tid; k < 2 * N1; k += kT) test(k < N1 ? N2 * k : N2 * (k - N1) + N2 - 1, eh, em);
+      barg<2>(eh, em, s, tid);
+      if (em >= 0 && (mb < 0 || higher(eh, em, hb, mb))) { hb = eh; mb = em; }
+      plat = fmax(plat, block_max<kNW>(tie, s.red_d, tid));
+    }
+    // Rescan the row when a reported plateau may outrank the best strict peak, or when the best peak ends up below the
+    // pivot launch's bound (the segments only tested samples above it: then it was not a bound - cannot happen while the
+    // bound is a value of the row itself, kept as insurance)
+    if ((plat > -INFINITY && (mb < 0 || plat >= hb)) || (pre.pfloor > -INFINITY && (mb < 0 || hb < pre.pfloor))) {
       eh = 0;
       em = -1;
       for (int m = 1 + tid; m <= n - 2; m += kT) test(m, eh, em);
