@@ -302,6 +302,7 @@ int Engine::forward_spectra(Plan& pl, const double* frames, size_t frame_stride,
     k_row_nonzero<<<dim3(rows), dim3(256), 0, stream>>>(frames, frame_stride, len, nonzero);
     PAL_HIP(hipGetLastError());
   }
+  if (pfa_forward_applies(pl, len)) return pfa_forward_spectra(pl, frames, frame_stride, rows, len, spectra);
   const Conv& c = pl.fwd;
   void* wsp = nullptr;
   PAL_TRY(scratch(0, size_t(chunk) * c.M() * sizeof(cd), &wsp));

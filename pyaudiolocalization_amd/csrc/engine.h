@@ -47,6 +47,7 @@ struct Pfa {
   int2* rowtab = nullptr;  // per row of Y: (u1 row mod N1, its step between outputs of a last-stage butterfly)
   // Rader variant of the row pass (pfa_rader.h) when N2 is prime and N2 - 1 = 11 x 9 x 10
   bool rader = false;
+  cd *rd_bhat_f = nullptr;   // forward direction (pfa_forward.h): FFT_L of exp(-2 pi i u2 g^s / N2) / L
   cd *rd_bhat = nullptr, *rd_tw2f = nullptr, *rd_tw2i = nullptr, *rd_tw3f = nullptr, *rd_tw3i = nullptr;
   int *rd_qidx = nullptr, *rd_ridx = nullptr;
   int rows() const { return (n1 + 1) / 2; }   // spectrum rows k1 <= (N1-1)/2 kept by the permuted layout
@@ -157,6 +158,9 @@ struct Engine {
   int pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, double* corr, size_t stride,
                            const int* zero_rows, const pal_phat_params& prm, int n2, pal_pair_record* table, int32_t* ksel_multi,
                            hipStream_t on);
+  bool pfa_forward_applies(const Plan& pl, int len) const;
+  int pfa_forward_spectra(Plan& pl, const double* frames, size_t frame_stride, int rows, int len, cd* spectra);
+  bool pfa_forward = true;    // PAL_PFA_FWD=0: forward spectra on the four-step route even where the prime-factor cut applies
   bool fuse_peaks = false;    // PAL_FUSED=1: column pass + peak statistics in one launch where it applies (pfa_cols_stats.h;
                               // measured break-even at 44.1 kHz x 1 s: the pivots then cost a pass over the grid)
 };

@@ -28,6 +28,7 @@
 #include "pfa_kernels.h"
 #include "pfa_rader.h"
 #include "pfa_cols_stats.h"
+#include "pfa_forward.h"
 
 namespace pal {
 
@@ -51,7 +52,7 @@ void Engine::free_pfa(Pfa& f) {
   if (f.r1) (void)hipFree(f.r1);
   if (f.T) (void)hipFree(f.T);
   if (f.rowtab) (void)hipFree(f.rowtab);
-  for (void* p : {(void*)f.rd_bhat, (void*)f.rd_tw2f, (void*)f.rd_tw2i, (void*)f.rd_tw3f, (void*)f.rd_tw3i, (void*)f.rd_qidx,
+  for (void* p : {(void*)f.rd_bhat, (void*)f.rd_bhat_f, (void*)f.rd_tw2f, (void*)f.rd_tw2i, (void*)f.rd_tw3f, (void*)f.rd_tw3i, (void*)f.rd_qidx,
                   (void*)f.rd_ridx})
     if (p) (void)hipFree(p);
   f = Pfa();
@@ -200,12 +201,24 @@ int Engine::build_rader(Pfa& f, long long n, long long u2) {
     }
     bhat[s] = mk(double(ar * scale), double(ai * scale));
   }
+  // forward direction: the kernel sequence is the conjugate one, B_f[k] = conj(B[-k]); scaled by 1 / L only
+  std::vector<cd> bhat_f(L);
+  for (int s = 0; s < L; ++s) {
+    long double ar = 0, ai = 0;
+    for (int k = 0; k < L; ++k) {
+      const int m = int((long long)s * k % L);
+      ar += br[k] * cr[m] + bi[k] * ci[m];                     // (br - i bi)(cr + i ci)
+      ai += br[k] * ci[m] - bi[k] * cr[m];
+    }
+    bhat_f[s] = mk(double(ar / (long double)L), double(ai / (long double)L));
+  }
   std::vector<cd> t2f, t2i, t3f, t3i;
   mixed_radix_twiddles(R2, R1, t2f);
   mixed_radix_twiddles(R2, R3, t2i);
   mixed_radix_twiddles(R3, R1 * R2, t3f);
   mixed_radix_twiddles(R1, R3 * R2, t3i);
   PAL_TRY(upload_table(this, bhat, &f.rd_bhat));
+  PAL_TRY(upload_table(this, bhat_f, &f.rd_bhat_f));
   PAL_TRY(upload_table(this, t2f, &f.rd_tw2f));
   PAL_TRY(upload_table(this, t2i, &f.rd_tw2i));
   PAL_TRY(upload_table(this, t3f, &f.rd_tw3f));
@@ -247,6 +260,40 @@ int Engine::pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads
     k_pfa_cols<kPfaTC, kPfaUnr><<<dim3(unsigned(G) * nblk, unsigned(f.nch + 3) / 4), dim3(256), 0, on>>>(Y, corr, stride, f.n1,
                                                                                                      f.n2, G, f.nch, f.T, zero_rows);
     PAL_HIP(hipGetLastError());
+  }
+  return PAL_OK;
+}
+
+// Forward spectra of `rows` real frames through the prime-factor cut (pfa_forward.h): two frames per transform, column
+// DFTs into the workspace, Rader rows into the SP layout.  Applies to plans with Rader rows and frames that leave the
+// upper half of the n points empty (len <= N2 (h + 1)).
+bool Engine::pfa_forward_applies(const Plan& pl, int len) const {
+  const Pfa& f = pl.pfa;
+  return pfa_forward && f.on() && f.rader && f.nch >= 1 && (len - 1) / f.n2 <= (f.n1 - 1) / 2;
+}
+
+int Engine::pfa_forward_spectra(Plan& pl, const double* frames, size_t frame_stride, int rows, int len, cd* spectra) {
+  const Pfa& f = pl.pfa;
+  void* wsp = nullptr;
+  PAL_TRY(scratch(0, size_t(chunk) * size_t(pl.n) * sizeof(cd), &wsp));
+  cd* Y = static_cast<cd*>(wsp);
+  for (int r0 = 0; r0 < rows; r0 += 2 * chunk) {
+    const int R = rows - r0 < 2 * chunk ? rows - r0 : 2 * chunk;   // frames of this group, two per transform
+    const int G = (R + 1) / 2;
+    {
+      ProfScope ps(this, "k_pfa_fwd_cols", stream);
+      const PfaFwdColsArgs a{frames + size_t(r0) * frame_stride, frame_stride, len, R, Y, f.T, f.n1, f.n2, G, f.nch};
+      const unsigned nblk = unsigned(f.n2 + 63) / 64;
+      k_pfa_fwd_cols<kPfaTC, kPfaUnr><<<dim3(unsigned(G) * nblk, unsigned(f.nch + 3) / 4), dim3(256), 0, stream>>>(a);
+      PAL_HIP(hipGetLastError());
+    }
+    {
+      ProfScope ps(this, "k_pfa_fwd_rows_rader<11,9,10>", stream);
+      const PfaFwdRowsArgs a{Y, spectra + size_t(r0) * pl.spec_stride(), f.rd_bhat_f, f.r1, f.rd_tw2f, f.rd_tw2i, f.rd_tw3f, f.rd_tw3i,
+                             f.rd_qidx, f.rowtab, f.n1, f.n2, f.rows(), G, R, 1.0f / float(f.n1)};
+      k_pfa_fwd_rows_rader<11, 9, 10><<<dim3(unsigned(G) * unsigned(f.rows())), dim3(256), 0, stream>>>(a);
+      PAL_HIP(hipGetLastError());
+    }
   }
   return PAL_OK;
 }

@@ -39,6 +39,66 @@ struct PfaRaderArgs {
   unsigned long long* stamps;   // diagnostics only (tools/microbench_pfa): 100 MHz clock reads of lane 0 per phase
 };
 
+// Stages 2-5 of the cyclic convolution on two L-point tiles in LDS (the radix-R1 first stage has filled them):
+// forward radix R2, the seam (radix R3, x the kernel spectrum `bhat`, inverse radix R3), inverse radix R2 and R1.
+// tw2f / tw2i: middle-stage twiddles in LDS; tw3f / tw3i / bhat: global memory, read at use.  Ends with a barrier.
+template <int R1, int R2, int R3>
+__device__ __forceinline__ void rader_convolve(const PlainTile& tile, const cd* tw2f, const cd* tw2i, const cd* __restrict__ tw3f,
+                                               const cd* __restrict__ tw3i, const cd* __restrict__ bhat, int tid) {
+  constexpr int L = R1 * R2 * R3, HALF = 128;
+  const int t = tid >> 7, i = tid & (HALF - 1);               // stage work item: tile, butterfly
+  const int is = i < L / R3 ? i : 0;                          // this lane's butterfly of the radix-R3 stages
+  // (the radix-R1 stages have 2 L / R1 = 180 butterflies: packed onto the first three wavefronts, the fourth only waits)
+  const int t1 = tid / (L / R1), i1 = tid % (L / R1);
+  const bool on1 = tid < 2 * (L / R1);
+  {
+    cd v[R2];
+    const bool on = i < L / R2;
+    if (on) mr_load<L, R2, R1, false>(tile, tw2f, t, i, v);
+    __syncthreads();
+    if (on) mr_store<L, R2, R1>(tile, t, i, v);
+    __syncthreads();
+  }
+  // seam: last forward stage (radix R3, outputs i + (L/R3) r), product with the kernel spectrum, first inverse
+  // stage (radix R3 of the order R3, R2, R1: the same L/R3-strided set of points)
+  {
+    cd v[R3];
+    const bool on = i < L / R3;
+    if (on) {
+      cd f[R3];                                               // (loaded here, not ahead: three wavefronts per SIMD hide the
+#pragma unroll                                                //  latency better than 116 more registers would)
+      for (int r = 1; r < R3; ++r) f[r] = tw3f[(r - 1) * (R1 * R2) + is];
+      mr_load_with<L, R3, false>(tile, t, i, v, f);
+#pragma unroll
+      for (int r = 0; r < R3; ++r) v[r] = cmul(v[r], bhat[is + (L / R3) * r]);
+      dft_sym<R3, true>(v);
+    }
+    __syncthreads();
+    if (on) mr_store<L, R3, 1>(tile, t, i, v);
+    __syncthreads();
+  }
+  {
+    cd v[R2];
+    const bool on = i < L / R2;
+    if (on) mr_load<L, R2, R3, true>(tile, tw2i, t, i, v);
+    __syncthreads();
+    if (on) mr_store<L, R2, R3>(tile, t, i, v);
+    __syncthreads();
+  }
+  {
+    cd v[R1];
+    if (on1) {
+      cd f[R1];
+#pragma unroll
+      for (int r = 1; r < R1; ++r) f[r] = tw3i[(r - 1) * (R3 * R2) + i1];
+      mr_load_with<L, R1, true>(tile, t1, i1, v, f);
+    }
+    __syncthreads();
+    if (on1) mr_store<L, R1, R3 * R2>(tile, t1, i1, v);
+    __syncthreads();
+  }
+}
+
 template <int R1, int R2, int R3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_pfa_rows_rader(PfaRaderArgs a) {
   constexpr int L = R1 * R2 * R3, HALF = 128;
@@ -52,7 +112,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   const int g = blockIdx.x % a.G, k1 = blockIdx.x / a.G;
   const int N1 = a.N1, N2 = a.N2;
   const PlainTile tile{data, L};
-  const int t = tid >> 7, i = tid & (HALF - 1);               // stage work item: tile, butterfly
   unsigned long long* const stamps = a.stamps;
   int stamp_at = 0;
   auto stamp = [&]() {
@@ -79,7 +138,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     const int e = tid + 256 * u;
     ri[u] = a.ridx[e < N2 ? e : N2 - 1];
   }
-  const int is = i < L / R3 ? i : 0;                          // this lane's butterfly of the radix-R3 stages
   // tile 0: R^p + i R^q at (k1, e);  tile 1: conj(R^p) + i conj(R^q) = the reversed row N1 - k1, held at the SAME
   // positions (it is transformed as the reversed sequence and its outputs are stored reversed)
   constexpr int NB1 = L / R1, HR = (R1 + 1) / 2;              // 90 butterflies per tile, 6 inputs per half-wavefront
@@ -123,60 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   __syncthreads();
   stamp();
 
-  // ---- forward: radix R2
-  // (the radix-R1 stages have 2 L / R1 = 180 butterflies: packed onto the first three wavefronts, the fourth only waits)
-  const int t1 = tid / (L / R1), i1 = tid % (L / R1);
-  const bool on1 = tid < 2 * (L / R1);
-  {
-    cd v[R2];
-    const bool on = i < L / R2;
-    if (on) mr_load<L, R2, R1, false>(tile, tw2f, t, i, v);
-    __syncthreads();
-    if (on) mr_store<L, R2, R1>(tile, t, i, v);
-    __syncthreads();
-  }
-  stamp();
-  // ---- seam: last forward stage (radix R3, outputs i + (L/R3) r), product with the kernel spectrum, first inverse
-  //      stage (radix R3 of the order R3, R2, R1: the same L/R3-strided set of points)
-  {
-    cd v[R3];
-    const bool on = i < L / R3;
-    if (on) {
-      cd f[R3];                                               // (loaded here, not ahead: three wavefronts per SIMD hide the
-#pragma unroll                                                //  latency better than 116 more registers would)
-      for (int r = 1; r < R3; ++r) f[r] = a.tw3f[(r - 1) * (R1 * R2) + is];
-      mr_load_with<L, R3, false>(tile, t, i, v, f);
-#pragma unroll
-      for (int r = 0; r < R3; ++r) v[r] = cmul(v[r], a.bhat[is + (L / R3) * r]);
-      dft_sym<R3, true>(v);
-    }
-    __syncthreads();
-    if (on) mr_store<L, R3, 1>(tile, t, i, v);
-    __syncthreads();
-  }
-  stamp();
-  // ---- inverse: radix R2, radix R1
-  {
-    cd v[R2];
-    const bool on = i < L / R2;
-    if (on) mr_load<L, R2, R3, true>(tile, tw2i, t, i, v);
-    __syncthreads();
-    if (on) mr_store<L, R2, R3>(tile, t, i, v);
-    __syncthreads();
-  }
-  {
-    cd v[R1];
-    if (on1) {
-      cd f[R1];
-#pragma unroll
-      for (int r = 1; r < R1; ++r) f[r] = a.tw3i[(r - 1) * (R3 * R2) + i1];
-      mr_load_with<L, R1, true>(tile, t1, i1, v, f);
-    }
-    __syncthreads();
-    if (on1) mr_store<L, R1, R3 * R2>(tile, t1, i1, v);
-    __syncthreads();
-  }
-
+  rader_convolve<R1, R2, R3>(tile, tw2f, tw2i, a.tw3f, a.tw3i, a.bhat, tid);
   stamp();
   // ---- epilogue: X[e] = x[0] + C[log_g e] (X[0] = sum of the inputs), column twiddle, store
   const cd x0 = cscale(dc[0], a.scale), z0 = cscale(dc[1], a.scale);

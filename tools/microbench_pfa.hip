@@ -405,7 +405,9 @@ int main(int argc, char** argv) {
     }
   }
   const dim3 cg(unsigned(G) * nblk, 1);
-  time_it("cols: product", 20, [&] { k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
+  time_it("cols: product", 20, [&] { k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T, nullptr); });
+  time_it("cols: product with 3 steps per batch", 20, [&] { k_pfa_cols<kPfaTC, 3><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T, nullptr); });
+  time_it("cols: product with 2 steps per batch", 20, [&] { k_pfa_cols<kPfaTC, 2><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T, nullptr); });
   time_it("cols: merged pairs, 11 t per wave, 1 step ahead", 20, [&] { cols_merged<11, 1><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
   time_it("cols: merged pairs, 11 t per wave, 2 steps/iter", 20, [&] { cols_merged<11, 2><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
   time_it("cols: merged pairs, 11 t per wave, 4 steps/iter", 20, [&] { cols_merged<11, 4><<<cg, dim3(256)>>>(Y, corr, stride, N1, N2, G, 4, T); });
@@ -445,8 +447,8 @@ int main(int argc, char** argv) {
       const int reps = 20;
       for (int i = 0; i < reps; ++i) {
         if (mode == 3 || mode == 4) {
-          k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, sa>>>(Y, corr, stride, N1, N2, G, 4, T);
-          k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, mode == 4 ? sb : sa>>>(Y2, corr2, stride, N1, N2, G, 4, T);
+          k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, sa>>>(Y, corr, stride, N1, N2, G, 4, T, nullptr);
+          k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, mode == 4 ? sb : sa>>>(Y2, corr2, stride, N1, N2, G, 4, T, nullptr);
         } else {
           k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, sa>>>(a);
           k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, mode == 6 ? sb : sa>>>(a2);
@@ -467,7 +469,7 @@ int main(int argc, char** argv) {
         const int reps = 20;
         for (int i = 0; i < reps; ++i) {
           if (mode != 1) k_pfa_rows_rader<11, 9, 10><<<dim3(grid), dim3(256), size_t(pad) * 1024, sa>>>(r2);
-          if (mode != 0) k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, mode == 2 ? sb : sa>>>(Y, corr, stride, N1, N2, G, 4, T);
+          if (mode != 0) k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, mode == 2 ? sb : sa>>>(Y, corr, stride, N1, N2, G, 4, T, nullptr);
         }
         CHECK(hipDeviceSynchronize());
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
@@ -479,7 +481,7 @@ int main(int argc, char** argv) {
       const int reps = 20;
       for (int i = 0; i < reps; ++i) {
         if (mode != 1) k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, sa>>>(a2);
-        if (mode != 0) k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, mode == 2 ? sb : sa>>>(Y, corr, stride, N1, N2, G, 4, T);
+        if (mode != 0) k_pfa_cols<kPfaTC, kPfaUnr><<<cg, dim3(256), 0, mode == 2 ? sb : sa>>>(Y, corr, stride, N1, N2, G, 4, T, nullptr);
       }
       CHECK(hipDeviceSynchronize());
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
