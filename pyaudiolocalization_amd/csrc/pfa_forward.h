@@ -43,46 +43,46 @@ __global__ __launch_bounds__(256) void k_pfa_fwd_cols(PfaFwdColsArgs a) {
   const double* xa = a.frames + size_t(2 * g) * a.stride;
   const double* xb = second ? xa + a.stride : xa;
   const int last = a.len - 1;
-  // branch-free loads: the index is clamped, samples beyond the frame (and the absent second frame) count as zero
-  auto load = [&](const double* x, int t, bool use) {
-    const int m = m2c + N2 * t;
-    const double v = x[m <= last ? m : last];
-    return use && m <= last ? v : 0.0;
-  };
+  // branch-free loads: the index is clamped and the value masked where it is USED (a select on the loaded value right
+  // behind the load would make every load wait for its data: the batches must stay in flight)
+  auto at = [&](int t) { const int m = m2c + N2 * t; return m <= last ? m : last; };
+  auto inside = [&](int t) { return m2c + N2 * t <= last; };
   double ac[TC], as[TC], bc[TC], bs[TC];
 #pragma unroll
   for (int tt = 0; tt < TC; ++tt) ac[tt] = as[tt] = bc[tt] = bs[tt] = 0.0;
   double suma = 0.0, sumb = 0.0;
-  const double a0 = load(xa, 0, true), b0 = load(xb, 0, second);
+  const double ra0 = xa[at(0)], rb0 = xb[at(0)];
   const double* Tj = a.T + size_t(ch) * 2 * TC;
   const size_t tstep = size_t(a.nch) * 2 * TC;
   double va[UNR], vb[UNR];
 #pragma unroll
   for (int u = 0; u < UNR; ++u) {
     const int t = 1 + u <= h ? 1 + u : h;
-    va[u] = load(xa, t, true);
-    vb[u] = load(xb, t, second);
+    va[u] = xa[at(t)];
+    vb[u] = xb[at(t)];
   }
+  const double a0 = inside(0) ? ra0 : 0.0, b0 = second && inside(0) ? rb0 : 0.0;
   for (int t = 1; t <= h; t += UNR) {
     double na[UNR], nb[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {                           // next batch; past the end the last step is re-read: no branch
       const int tn = t + UNR + u <= h ? t + UNR + u : h;
-      na[u] = load(xa, tn, true);
-      nb[u] = load(xb, tn, second);
+      na[u] = xa[at(tn)];
+      nb[u] = xb[at(tn)];
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u, Tj += tstep) {              // steps beyond h meet zero rows of the table
-      const bool in = t + u <= h;
-      suma += in ? va[u] : 0.0;
-      sumb += in ? vb[u] : 0.0;
+      const bool in = t + u <= h && inside(t + u);
+      const double av = in ? va[u] : 0.0, bv = in && second ? vb[u] : 0.0;
+      suma += av;
+      sumb += bv;
 #pragma unroll
       for (int tt = 0; tt < TC; ++tt) {
         const double c = Tj[tt], sn = Tj[TC + tt];
-        ac[tt] = __builtin_fma(c, va[u], ac[tt]);
-        as[tt] = __builtin_fma(sn, va[u], as[tt]);
-        bc[tt] = __builtin_fma(c, vb[u], bc[tt]);
-        bs[tt] = __builtin_fma(sn, vb[u], bs[tt]);
+        ac[tt] = __builtin_fma(c, av, ac[tt]);
+        as[tt] = __builtin_fma(sn, av, as[tt]);
+        bc[tt] = __builtin_fma(c, bv, bc[tt]);
+        bs[tt] = __builtin_fma(sn, bv, bs[tt]);
       }
     }
 #pragma unroll

@@ -92,6 +92,43 @@ def test_rader_rows_match_chirp_convolution_rows(engine, monkeypatch):
             assert np.array_equal(t1[b][name], want[name]), name
 
 
+def test_forward_spectra_through_the_prime_factor_cut(engine, monkeypatch):
+    """Plans with Rader rows take the forward transform through the same cut (pfa_forward.h: two real frames per transform);
+    PAL_PFA_FWD=0 keeps the four-step chirp convolution.  Odd frame counts, unequal lengths, a silent frame."""
+    from pyaudiolocalization_amd import Engine
+    rng = np.random.default_rng(4)
+    engine.profile_begin()
+    engine.gcc_phat_all_pairs(rng.standard_normal((1, 3, 496)), 16000.0)
+    engine.profile_end()
+    assert engine.profile_entries()["k_pfa_fwd_cols"][1] >= 1
+    monkeypatch.setenv("PAL_PFA_FWD", "0")
+    plain = Engine(engine.device)
+    try:
+        for mics, length, fs, med in ((3, 496, 16000.0, None), (5, 496, 8000.0, 0.01), (3, 44100, 44100.0, 0.05)):
+            frames = rng.standard_normal((2, mics, length))
+            frames[:, 1:] += 0.5 * frames[:, :1]
+            frames[1, 0] = 0.0
+            t1, c1 = engine.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, want_corr=True)
+            plain.profile_begin()
+            t0, c0 = plain.gcc_phat_all_pairs(frames, fs, max_expected_delay=med, want_corr=True)
+            plain.profile_end()
+            assert "k_pfa_fwd_cols" not in plain.profile_entries()
+            assert np.max(np.abs(c1 - c0)) <= 1e-13
+            for name in ("k_sel", "branch", "k_argmax", "n_sel"):
+                assert np.array_equal(t1[name], t0[name]), name
+            if length < 1000:
+                for b in range(2):
+                    want = O.all_pairs(frames[b], fs, max_expected_delay=med)
+                    for name in ("k_sel", "branch", "k_argmax"):
+                        assert np.array_equal(t1[b][name], want[name]), name
+        a, b = rng.standard_normal(600), rng.standard_normal(392)       # n = 991 with unequal lengths
+        want = O.phat_correlation(a, b)
+        assert np.max(np.abs(engine.phat_correlation(a, b) - want)) <= 5e-14
+        assert np.max(np.abs(plain.phat_correlation(a, b) - want)) <= 5e-14
+    finally:
+        plain.close()
+
+
 def test_prime_factor_route_odd_pair_counts_and_tables(engine, monkeypatch):
     """5 mics = 10 pairs = 5 packed transforms, 3 mics = 3 pairs (one half-empty transform): tables and
     sequences of the prime-factor route equal the four-step route's."""
