@@ -207,8 +207,10 @@ def main() -> None:
                                       + (f"Rader row DFTs, cyclic convolutions of {info['n2'] - 1} points in LDS"
                                          if info['tile_len'] & (info['tile_len'] - 1) else
                                          f"in-LDS chirp convolutions of {info['tile_len']} points")
-                                      + f" + dense column DFTs; forward spectra via chirp convolution "
-                                      f"{info['m1']}x{info['m2']})" if info.get("n1") else
+                                      + " + dense column DFTs; forward spectra "
+                                      + ("through the same cut, two real frames per transform)"
+                                         if info['tile_len'] & (info['tile_len'] - 1) and os.environ.get("PAL_PFA_FWD", "1") != "0" else
+                                         f"via chirp convolution {info['m1']}x{info['m2']})") if info.get("n1") else
                                       f" via chirp convolution {info['m1']}x{info['m2']}"),
                        "frames_per_step_per_gpu": b, "mics": m, "samples": length, "pairs_per_frame": pairs,
                        "gather": gather, "parallelism": f"frames sharded over {world} GPU(s)"},
