@@ -395,11 +395,11 @@ int main(int argc, char** argv) {
     CHECK(hipDeviceSynchronize());
     std::vector<unsigned long long> hs(size_t(8) * grid);
     CHECK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
-    const char* names[6] = {"loads + whiten + radix 11", "forward radix 9", "seam", "inverse radix 9, 11", "epilogue", "total"};
-    for (int ph = 0; ph < 6; ++ph) {
+    const char* names[4] = {"loads + whiten + radix 11", "radix 9, seam, inverse 9 / 11", "epilogue", "total"};
+    for (int ph = 0; ph < 4; ++ph) {
       std::vector<double> d(grid);
       for (unsigned w = 0; w < grid; ++w)
-        d[w] = ph < 5 ? double(hs[size_t(w) * 8 + ph + 1] - hs[size_t(w) * 8 + ph]) / 100.0 : double(hs[size_t(w) * 8 + 5] - hs[size_t(w) * 8]) / 100.0;
+        d[w] = ph < 3 ? double(hs[size_t(w) * 8 + ph + 1] - hs[size_t(w) * 8 + ph]) / 100.0 : double(hs[size_t(w) * 8 + 3] - hs[size_t(w) * 8]) / 100.0;
       std::sort(d.begin(), d.end());
       printf("  rader phase %-26s median %6.2f us  p90 %6.2f us\n", names[ph], d[grid / 2], d[grid * 9 / 10]);
     }
