@@ -47,7 +47,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=8, help="frames per step per GPU (one batch = one step)")
+    ap.add_argument("--frames", type=int, default=16, help="frames per step per GPU (one batch = one step)")
     ap.add_argument("--mics", type=int, default=64)
     ap.add_argument("--length", type=int, default=44100)
     ap.add_argument("--max-expected-delay", type=float, default=0.05, help="seconds; negative = None")
