@@ -88,6 +88,37 @@ template <int R, bool INV> PAL_HD void dft_sym(cd* v) {
   for (int r = 0; r < R; ++r) v[r] = out[r];
 }
 
+// length 10 = 2 x 5 by the prime-factor map (no twiddles between coprime factors): inputs n = 5 n1 + 2 n2, outputs
+// k = 5 k1 + 6 k2 (mod 10): five radix-2 butterflies, then two length-5 DFTs in the symmetric form.  92 real
+// operations against 124 for the generic form above; the seam of the Rader row pass runs two of these per lane.
+template <bool INV> PAL_HD void dft5_sym(cd& u0, cd& u1, cd& u2, cd& u3, cd& u4) {
+  constexpr double c1 = Roots<10>::c(2), c2 = Roots<10>::c(4), s1 = Roots<10>::s(2), s2 = Roots<10>::s(4);   // 2 pi / 5, 4 pi / 5
+  const cd a1 = u1 + u4, a2 = u2 + u3, b1 = u1 - u4, b2 = u2 - u3;
+  const cd x0 = u0;
+  u0 = x0 + a1 + a2;
+  const cd cr1 = mk(__builtin_fma(c2, a2.x, __builtin_fma(c1, a1.x, x0.x)), __builtin_fma(c2, a2.y, __builtin_fma(c1, a1.y, x0.y)));
+  const cd cr2 = mk(__builtin_fma(c1, a2.x, __builtin_fma(c2, a1.x, x0.x)), __builtin_fma(c1, a2.y, __builtin_fma(c2, a1.y, x0.y)));
+  const cd si1 = mk(__builtin_fma(s2, b2.x, s1 * b1.x), __builtin_fma(s2, b2.y, s1 * b1.y));
+  const cd si2 = mk(__builtin_fma(-s1, b2.x, s2 * b1.x), __builtin_fma(-s1, b2.y, s2 * b1.y));
+  // forward: X_m = cr - i si, X_{5-m} = cr + i si; the inverse swaps them
+  const cd lo1 = mk(cr1.x + si1.y, cr1.y - si1.x), hi1 = mk(cr1.x - si1.y, cr1.y + si1.x);
+  const cd lo2 = mk(cr2.x + si2.y, cr2.y - si2.x), hi2 = mk(cr2.x - si2.y, cr2.y + si2.x);
+  u1 = INV ? hi1 : lo1;
+  u4 = INV ? lo1 : hi1;
+  u2 = INV ? hi2 : lo2;
+  u3 = INV ? lo2 : hi2;
+}
+template <bool INV> PAL_HD void dft10_pfa(cd* v) {
+  cd e0 = v[0] + v[5], e1 = v[2] + v[7], e2 = v[4] + v[9], e3 = v[6] + v[1], e4 = v[8] + v[3];   // k1 = 0
+  cd o0 = v[0] - v[5], o1 = v[2] - v[7], o2 = v[4] - v[9], o3 = v[6] - v[1], o4 = v[8] - v[3];   // k1 = 1
+  dft5_sym<INV>(e0, e1, e2, e3, e4);
+  dft5_sym<INV>(o0, o1, o2, o3, o4);
+  v[0] = e0; v[6] = e1; v[2] = e2; v[8] = e3; v[4] = e4;       // k = 6 k2 mod 10
+  v[5] = o0; v[1] = o1; v[7] = o2; v[3] = o3; v[9] = o4;       // k = 5 + 6 k2 mod 10
+}
+template <> PAL_HD void dft_sym<10, false>(cd* v) { dft10_pfa<false>(v); }
+template <> PAL_HD void dft_sym<10, true>(cd* v) { dft10_pfa<true>(v); }
+
 // plain (unswizzled) tile of `pitch` elements per sub-transform: the odd strides of these stages spread over the banks
 struct PlainTile {
   static constexpr bool kLds = true;
