@@ -48,7 +48,7 @@ struct Pfa {
   // Rader variant of the row pass (pfa_rader.h) when N2 is prime and N2 - 1 = 11 x 9 x 10
   bool rader = false;
   cd *rd_bhat_f = nullptr;   // forward direction (pfa_forward.h): FFT_L of exp(-2 pi i u2 g^s / N2) / L
-  cd *rd_bhat = nullptr, *rd_tw2f = nullptr, *rd_tw2i = nullptr, *rd_tw3f = nullptr, *rd_tw3i = nullptr;
+  cd* rd_bhat = nullptr;     // 3-D spectrum of the Rader kernel sequence in prime-factor positions (mixed_radix.h)
   int *rd_qidx = nullptr, *rd_ridx = nullptr;
   int rows() const { return (n1 + 1) / 2; }   // spectrum rows k1 <= (N1-1)/2 kept by the permuted layout
   bool on() const { return n1 > 0; }

@@ -1,4 +1,4 @@
-// mixed_radix.h - radix 9 / 10 / 11 butterflies and the mixed-radix Stockham stages of the Rader row pass (gfx950,
+// mixed_radix.h - radix 9 / 10 / 11 butterflies and the prime-factor stages of the Rader row pass (gfx950,
 // fp64).  Rader's algorithm turns the N2-point DFT of a prime N2 into a cyclic convolution of length N2 - 1; for
 // N2 = 991 that is 990 = 11 x 9 x 10 points instead of the 2048-point chirp convolution (pfa_rader.h).
 //
@@ -128,39 +128,31 @@ struct PlainTile {
   PAL_HD void operator()(int t, int e, cd v) const { data[t * pitch + e] = v; }
 };
 
-// Stockham autosort stage of an N-point transform: radix R, P = product of the radices of the earlier stages.
-// Butterfly i < N / R of sub-transform t reads elements i + r N/R, applies exp(-/+ 2 pi i k r / (P R)) with k = i mod P
-// (`tws[(r-1) P + k]`, forward values; or `f[r]` handed over in registers) and the length-R DFT; its outputs belong at
-// (i - k) R + k + r P.
-template <int N, int R, int P, bool INV, class In> PAL_HD void mr_load(const In& in, const cd* tws, int t, int i, cd* v) {
-  constexpr int NB = N / R;
-#pragma unroll
-  for (int r = 0; r < R; ++r) v[r] = in(t, i + r * NB);
-  if (P > 1) {
-    const int k = i % P;
-#pragma unroll
-    for (int r = 1; r < R; ++r) {
-      const cd f = tws[(r - 1) * P + k];
-      v[r] = INV ? cmulc(v[r], f) : cmul(v[r], f);
-    }
-  }
-  dft_sym<R, INV>(v);
-}
+// The cyclic convolution of length L = R1 R2 R3 with pairwise coprime factors (990 = 11 x 9 x 10) needs no twiddles at
+// all: s -> (s mod R2, s mod R3, s mod R1) is a ring isomorphism of Z_L onto Z_R2 x Z_R3 x Z_R1, so the convolution
+// over Z_L is a three-dimensional cyclic convolution in those coordinates, and the separable 3-D DFT (plain length-R
+// DFTs along each axis) diagonalises it.  Element s lives at
+//     pos(s) = (s mod R2) + R2 (s mod R3) + R2 R3 (s mod R1)
+// of its tile.  A stage is the set of butterflies along one axis: every butterfly reads and writes the SAME R elements
+// (in place, no autosort), so a stage needs one barrier (behind its stores) instead of two, and the three axes can run
+// in any order.
+template <int R1, int R2, int R3> struct Axes {
+  static constexpr int L = R1 * R2 * R3;
+  PAL_HD static constexpr int pos(int s) { return s % R2 + R2 * (s % R3) + R2 * R3 * (s % R1); }
+  // butterfly j of the stage along an axis: first element and element stride
+  PAL_HD static constexpr int base1(int j) { return j; }                                  // axis R1: j < R2 R3, stride R2 R3
+  PAL_HD static constexpr int base2(int j) { return R2 * j; }                             // axis R2: j < R3 R1, stride 1
+  PAL_HD static constexpr int base3(int j) { return j % R2 + R2 * R3 * (j / R2); }        // axis R3: j < R2 R1, stride R2
+  static constexpr int kStride1 = R2 * R3, kStride2 = 1, kStride3 = R2;
+};
 
-template <int N, int R, bool INV, class In> PAL_HD void mr_load_with(const In& in, int t, int i, cd* v, const cd* f) {
-  constexpr int NB = N / R;
+template <int R, class In> PAL_HD void axis_load(const In& in, int t, int base, int stride, cd* v) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) v[r] = in(t, i + r * NB);
-#pragma unroll
-  for (int r = 1; r < R; ++r) v[r] = INV ? cmulc(v[r], f[r]) : cmul(v[r], f[r]);
-  dft_sym<R, INV>(v);
+  for (int r = 0; r < R; ++r) v[r] = in(t, base + r * stride);
 }
-
-template <int N, int R, int P, class Out> PAL_HD void mr_store(const Out& out, int t, int i, const cd* v) {
-  const int k = i % P;
-  const int j0 = (i - k) * R + k;
+template <int R, class Out> PAL_HD void axis_store(const Out& out, int t, int base, int stride, const cd* v) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) out(t, j0 + r * P, v[r]);
+  for (int r = 0; r < R; ++r) out(t, base + r * stride, v[r]);
 }
 
 }  // namespace pal

@@ -52,7 +52,7 @@ void Engine::free_pfa(Pfa& f) {
   if (f.r1) (void)hipFree(f.r1);
   if (f.T) (void)hipFree(f.T);
   if (f.rowtab) (void)hipFree(f.rowtab);
-  for (void* p : {(void*)f.rd_bhat, (void*)f.rd_bhat_f, (void*)f.rd_tw2f, (void*)f.rd_tw2i, (void*)f.rd_tw3f, (void*)f.rd_tw3i, (void*)f.rd_qidx,
+  for (void* p : {(void*)f.rd_bhat, (void*)f.rd_bhat_f, (void*)f.rd_qidx,
                   (void*)f.rd_ridx})
     if (p) (void)hipFree(p);
   f = Pfa();
@@ -135,24 +135,13 @@ int Engine::build_pfa(Plan& pl) {
   return PAL_OK;
 }
 
-// exp(-2 pi i k r / (P R)) at [(r-1) P + k]: twiddles of a mixed-radix stage (mixed_radix.h), long-double accurate
-static void mixed_radix_twiddles(int R, int P, std::vector<cd>& tw) {
-  const long double two_pi = 6.283185307179586476925286766559005768L;
-  tw.assign(size_t(R - 1) * P, mk(0, 0));
-  for (int r = 1; r < R; ++r)
-    for (int k = 0; k < P; ++k) {
-      const long double ang = -two_pi * (long double)((long long)k * r % ((long long)P * R)) / (long double)((long long)P * R);
-      tw[size_t(r - 1) * P + k] = mk(double(cosl(ang)), double(sinl(ang)));
-    }
-}
-
 template <class T> static int upload_table(Engine* e, const std::vector<T>& host, T** dev) {
   if (hipMalloc(dev, host.size() * sizeof(T)) != hipSuccess) return e->fail(PAL_ERR_NOMEM, "rader tables");
   return e->check(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice), "rader tables");
 }
 
-// Rader tables of the prime N2 = f.n2 (pfa_rader.h): generator re-indexing, the spectrum of w^(g^s) with
-// w = exp(2 pi i u2 / N2), and the twiddles of the 11 x 9 x 10 (forward) / 10 x 9 x 11 (inverse) stage orders
+// Rader tables of the prime N2 = f.n2 (pfa_rader.h): generator re-indexing into prime-factor positions and the 3-D
+// spectra of the kernel sequences w^(g^s), w = exp(+/- 2 pi i u2 / N2)
 int Engine::build_rader(Pfa& f, long long n, long long u2) {
   constexpr int R1 = 11, R2 = 9, R3 = 10;
   const int p = f.n2, L = p - 1;
@@ -169,60 +158,50 @@ int Engine::build_rader(Pfa& f, long long n, long long u2) {
     if (ok) g = c;
   }
   if (!g) return PAL_OK;
+  using AX = Axes<R1, R2, R3>;                                 // prime-factor positions of the convolution index (mixed_radix.h)
   std::vector<int> gpow(L), qidx(p, 0), ridx(p, 0);
   long long x = 1;
   for (int s = 0; s < L; ++s, x = x * g % p) gpow[s] = int(x);
   for (int s = 0; s < L; ++s) {
-    ridx[gpow[s]] = s;                                         // X[g^s] = x[0] + C[s]
-    qidx[gpow[(L - s) % L]] = s;                               // a[s] = x[g^-s]
+    ridx[gpow[s]] = AX::pos(s);                                // X[g^s] = x[0] + C[s]
+    qidx[gpow[(L - s) % L]] = AX::pos(s);                      // a[s] = x[g^-s]
   }
   qidx[0] = L;                                                 // the rows of SP keep this order, bin 0 last
   const long double two_pi = 6.283185307179586476925286766559005768L;
-  std::vector<long double> br(L), bi(L);
+  std::vector<long double> br(L), bi(L);                       // kernel sequence b[s] = w^(g^s), w = exp(2 pi i u2 / N2)
   for (int s = 0; s < L; ++s) {
     const long double ang = two_pi * (long double)(u2 * gpow[s] % p) / (long double)p;
     br[s] = cosl(ang);
     bi[s] = sinl(ang);
   }
-  std::vector<long double> cr(L), ci(L);
+  std::vector<long double> cr(L), ci(L);                       // exp(-2 pi i m / L)
   for (int s = 0; s < L; ++s) {
     const long double ang = -two_pi * (long double)s / (long double)L;
     cr[s] = cosl(ang);
     ci[s] = sinl(ang);
   }
-  std::vector<cd> bhat(L);
+  // 3-D spectrum at position k2 + R2 k3 + R2 R3 k1: sum_s b[s] exp(-2 pi i ((s mod R2) k2 / R2 + (s mod R3) k3 / R3 + (s mod R1) k1 / R1));
+  // inverse direction scaled by 1 / (L n) (the unnormalised inverse stages and numpy's 1 / n), forward direction (the
+  // conjugate sequence) by 1 / L
+  std::vector<cd> bhat(L), bhat_f(L);
   const long double scale = 1.0L / ((long double)L * (long double)n);
-  for (int s = 0; s < L; ++s) {
-    long double ar = 0, ai = 0;
-    for (int k = 0; k < L; ++k) {
-      const int m = int((long long)s * k % L);
-      ar += br[k] * cr[m] - bi[k] * ci[m];
-      ai += br[k] * ci[m] + bi[k] * cr[m];
-    }
-    bhat[s] = mk(double(ar * scale), double(ai * scale));
-  }
-  // forward direction: the kernel sequence is the conjugate one, B_f[k] = conj(B[-k]); scaled by 1 / L only
-  std::vector<cd> bhat_f(L);
-  for (int s = 0; s < L; ++s) {
-    long double ar = 0, ai = 0;
-    for (int k = 0; k < L; ++k) {
-      const int m = int((long long)s * k % L);
-      ar += br[k] * cr[m] + bi[k] * ci[m];                     // (br - i bi)(cr + i ci)
-      ai += br[k] * ci[m] - bi[k] * cr[m];
-    }
-    bhat_f[s] = mk(double(ar / (long double)L), double(ai / (long double)L));
-  }
-  std::vector<cd> t2f, t2i, t3f, t3i;
-  mixed_radix_twiddles(R2, R1, t2f);
-  mixed_radix_twiddles(R2, R3, t2i);
-  mixed_radix_twiddles(R3, R1 * R2, t3f);
-  mixed_radix_twiddles(R1, R3 * R2, t3i);
+  for (int k1 = 0; k1 < R1; ++k1)
+    for (int k3 = 0; k3 < R3; ++k3)
+      for (int k2 = 0; k2 < R2; ++k2) {
+        long double ar = 0, ai = 0, fr = 0, fi = 0;
+        for (int s = 0; s < L; ++s) {
+          const int m = int(((long long)(s % R2) * k2 * (L / R2) + (long long)(s % R3) * k3 * (L / R3) + (long long)(s % R1) * k1 * (L / R1)) % L);
+          ar += br[s] * cr[m] - bi[s] * ci[m];
+          ai += br[s] * ci[m] + bi[s] * cr[m];
+          fr += br[s] * cr[m] + bi[s] * ci[m];                 // (br - i bi)(cr + i ci)
+          fi += br[s] * ci[m] - bi[s] * cr[m];
+        }
+        const size_t at = size_t(k2) + size_t(R2) * k3 + size_t(R2) * R3 * k1;
+        bhat[at] = mk(double(ar * scale), double(ai * scale));
+        bhat_f[at] = mk(double(fr / (long double)L), double(fi / (long double)L));
+      }
   PAL_TRY(upload_table(this, bhat, &f.rd_bhat));
   PAL_TRY(upload_table(this, bhat_f, &f.rd_bhat_f));
-  PAL_TRY(upload_table(this, t2f, &f.rd_tw2f));
-  PAL_TRY(upload_table(this, t2i, &f.rd_tw2i));
-  PAL_TRY(upload_table(this, t3f, &f.rd_tw3f));
-  PAL_TRY(upload_table(this, t3i, &f.rd_tw3i));
   PAL_TRY(upload_table(this, qidx, &f.rd_qidx));
   PAL_TRY(upload_table(this, ridx, &f.rd_ridx));
   f.rader = true;
@@ -234,7 +213,7 @@ int Engine::pfa_rows(const Plan& pl, const cd* permuted, const int4* quads, int 
   const cd* tws = f.lm >= 11 ? stage_table_compact(f.lm) : stage_table(f.lm);
   if (f.rader) {
     ProfScope ps(this, "k_pfa_rows_rader<11,9,10>", on);
-    PfaRaderArgs a{permuted, quads, Y, f.rd_bhat, f.r1, f.rd_tw2f, f.rd_tw2i, f.rd_tw3f, f.rd_tw3i, f.rd_ridx, f.rowtab,
+    PfaRaderArgs a{permuted, quads, Y, f.rd_bhat, f.r1, f.rd_ridx, f.rowtab,
                    f.n1, f.n2, f.rows(), G, 1.0f / float(f.n1), 1.0 / double(pl.n), nullptr};
     k_pfa_rows_rader<11, 9, 10><<<dim3(unsigned(G) * unsigned(f.rows())), dim3(256), 0, on>>>(a);
     PAL_HIP(hipGetLastError());
@@ -289,7 +268,7 @@ int Engine::pfa_forward_spectra(Plan& pl, const double* frames, size_t frame_str
     }
     {
       ProfScope ps(this, "k_pfa_fwd_rows_rader<11,9,10>", stream);
-      const PfaFwdRowsArgs a{Y, spectra + size_t(r0) * pl.spec_stride(), f.rd_bhat_f, f.r1, f.rd_tw2f, f.rd_tw2i, f.rd_tw3f, f.rd_tw3i,
+      const PfaFwdRowsArgs a{Y, spectra + size_t(r0) * pl.spec_stride(), f.rd_bhat_f, f.r1,
                              f.rd_qidx, f.rowtab, f.n1, f.n2, f.rows(), G, R, 1.0f / float(f.n1)};
       k_pfa_fwd_rows_rader<11, 9, 10><<<dim3(unsigned(G) * unsigned(f.rows())), dim3(256), 0, stream>>>(a);
       PAL_HIP(hipGetLastError());

@@ -104,10 +104,9 @@ __global__ __launch_bounds__(256) void k_pfa_fwd_cols(PfaFwdColsArgs a) {
 struct PfaFwdRowsArgs {
   const cd* Y;           // [G][N1][N2] column DFTs
   cd* SP;                // [rows][NR][N2] spectra of this group's frames, rows in generator order
-  const cd* bhat;        // FFT_L of w^(g^s) with w = exp(-2 pi i u2 / N2), scaled by 1 / L
+  const cd* bhat;        // 3-D spectrum (prime-factor positions) of w^(g^s) with w = exp(-2 pi i u2 / N2), scaled by 1 / L
   const cd* r1;          // exp(-2 pi i q / N1)
-  const cd *tw2f, *tw2i, *tw3f, *tw3i;   // stage twiddles (pfa_rader.h)
-  const int* qidx;       // [N2]: position -log_g e of input column e (entry 0: L)
+  const int* qidx;       // [N2]: position pos(-log_g e) of input column e (entry 0: L)
   const int2* rowtab;    // per row of Y: (u1 row mod N1, -)
   int N1, N2, NR, G, rows;
   float inv;             // 1 / N1
@@ -118,8 +117,6 @@ template <int R1, int R2, int R3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_pfa_fwd_rows_rader(PfaFwdRowsArgs a) {
   constexpr int L = R1 * R2 * R3;
   __shared__ cd data[2 * L];
-  __shared__ cd tw2f[(R2 - 1) * R1];
-  __shared__ cd tw2i[(R2 - 1) * R3];
   __shared__ cd part[4][2];            // per wavefront: sum of the tile-0 / tile-1 inputs
   __shared__ cd dc[2];                 // input column 0 of both tiles
   const int tid = threadIdx.x;
@@ -127,8 +124,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   const int N1 = a.N1, N2 = a.N2;
   const unsigned n1 = unsigned(N1);
   const PlainTile tile{data, L};
-  for (int k = tid; k < (R2 - 1) * R1; k += 256) tw2f[k] = a.tw2f[k];
-  for (int k = tid; k < (R2 - 1) * R3; k += 256) tw2i[k] = a.tw2i[k];
   const int kr = k1 ? N1 - k1 : 0;
   const cd* y0 = a.Y + (size_t(g) * N1 + k1) * N2;
   const cd* y1 = a.Y + (size_t(g) * N1 + kr) * N2;
@@ -170,19 +165,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   }
   if ((tid & 63) == 0) { part[tid >> 6][0] = sx; part[tid >> 6][1] = sz; }
   __syncthreads();
-  // ---- the cyclic convolution: radix R1 first stage, then the shared stages
+  // ---- the cyclic convolution: first stage along axis R1 (in place), then the shared stages
+  using AX = Axes<R1, R2, R3>;
   {
     const int t1 = tid / (L / R1), i1 = tid % (L / R1);
-    const bool on1 = tid < 2 * (L / R1);
     cd v[R1];
-    if (on1) mr_load<L, R1, 1, false>(tile, nullptr, t1, i1, v);
-    __syncthreads();
-    if (on1) mr_store<L, R1, 1>(tile, t1, i1, v);
+    if (tid < 2 * (L / R1)) {
+      axis_load<R1>(tile, t1, AX::base1(i1), AX::kStride1, v);
+      dft_sym<R1, false>(v);
+      axis_store<R1>(tile, t1, AX::base1(i1), AX::kStride1, v);
+    }
     __syncthreads();
   }
-  rader_convolve<R1, R2, R3>(tile, tw2f, tw2i, a.tw3f, a.tw3i, a.bhat, tid);
-  // ---- epilogue: output position p holds bin k2 = g^-p: Z[k1, k2] = x[0] + C0[-p], Z[N1 - k1, N2 - k2] = x'[0] + C1[-p + L/2]
-  //      (-1 = g^(L/2)); separate the two frames and store both spectra rows coalesced
+  rader_convolve<R1, R2, R3>(tile, a.bhat, tid);
+  // ---- epilogue: output position p = pos(q) holds bin k2 = g^-q: Z[k1, k2] = x[0] + C0[pos(-q)] and
+  //      Z[N1 - k1, N2 - k2] = x'[0] + C1[pos(-q + L/2)] (-1 = g^(L/2)).  pos() is a ring isomorphism, so both are
+  //      coordinate-wise: negate the residues, add L/2 mod (R2, R3, R1).  Separate the two frames, store coalesced.
   const cd x0 = dc[0], z0 = dc[1];
   const cd sum0 = part[0][0] + part[1][0] + part[2][0] + part[3][0];
   const cd sum1 = part[0][1] + part[1][1] + part[2][1] + part[3][1];
@@ -196,10 +194,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     if (p < N2) {
       cd Z0, Z1;
       if (p < L) {
-        const int r = p ? L - p : 0;
-        const int r2 = r + L / 2 < L ? r + L / 2 : r - L / 2;
-        Z0 = x0 + data[r];
-        Z1 = z0 + data[L + r2];
+        const int i2 = p % R2, i3 = (p / R2) % R3, i1 = p / (R2 * R3);
+        const int n2 = i2 ? R2 - i2 : 0, n3 = i3 ? R3 - i3 : 0, n1 = i1 ? R1 - i1 : 0;        // -q
+        constexpr int h2 = (L / 2) % R2, h3 = (L / 2) % R3, h1 = (L / 2) % R1;
+        const int m2 = n2 + h2 < R2 ? n2 + h2 : n2 + h2 - R2, m3 = n3 + h3 < R3 ? n3 + h3 : n3 + h3 - R3,
+                  m1 = n1 + h1 < R1 ? n1 + h1 : n1 + h1 - R1;                                     // -q + L/2
+        Z0 = x0 + data[n2 + R2 * n3 + R2 * R3 * n1];
+        Z1 = z0 + data[L + m2 + R2 * m3 + R2 * R3 * m1];
       } else {                                                // bin 0: the plain sums
         Z0 = sum0;
         Z1 = sum1;

@@ -24,14 +24,12 @@
 namespace pal {
 
 struct PfaRaderArgs {
-  const cd* SP;          // permuted spectra [mic][NR][N2], rows in generator order: x[g^-s] at s < L, x[0] at L
+  const cd* SP;          // permuted spectra [mic][NR][N2], rows in generator order: x[g^-s] at pos(s), x[0] at L
   const int4* quad;      // mic rows (a, b) of pair p and (c, d) of pair q; c < 0: no second pair
   cd* Y;                 // [G][N1][N2]
-  const cd* bhat;        // FFT_L of w^(g^s), scaled by 1 / (L n)
+  const cd* bhat;        // 3-D spectrum of w^(g^s) in prime-factor positions, scaled by 1 / (L n)
   const cd* r1;          // exp(-2 pi i q / N1)
-  const cd *tw2f, *tw2i; // middle-stage twiddles: forward order (radix R2 after R1), inverse order (radix R2 after R3)
-  const cd *tw3f, *tw3i; // last-stage twiddles: forward (radix R3, P = R1 R2), inverse (radix R1, P = R3 R2)
-  const int* ridx;       // [N2]: log_g e (entry 0 unused)
+  const int* ridx;       // [N2]: position of log_g e (entry 0 unused)
   const int2* rowtab;    // per row of Y: (u1 row mod N1, -)
   int N1, N2, NR, G;
   float inv;             // 1 / N1
@@ -39,62 +37,56 @@ struct PfaRaderArgs {
   unsigned long long* stamps;   // diagnostics only (tools/microbench_pfa): 100 MHz clock reads of lane 0 per phase
 };
 
-// Stages 2-5 of the cyclic convolution on two L-point tiles in LDS (the radix-R1 first stage has filled them):
-// forward radix R2, the seam (radix R3, x the kernel spectrum `bhat`, inverse radix R3), inverse radix R2 and R1.
-// tw2f / tw2i: middle-stage twiddles in LDS; tw3f / tw3i / bhat: global memory, read at use.  Ends with a barrier.
+// Stages 2-5 of the cyclic convolution on two L-point tiles in LDS (the first stage, along axis R1, has filled them):
+// in prime-factor coordinates (mixed_radix.h) the convolution is three-dimensional and its stages are plain DFTs along
+// one axis each, in place and without twiddles: forward along R2, the seam along R3 (forward DFT, x the kernel's 3-D
+// spectrum `bhat`, inverse DFT on the same registers), inverse along R2 and R1.  One barrier per stage; ends with one.
 template <int R1, int R2, int R3>
-__device__ __forceinline__ void rader_convolve(const PlainTile& tile, const cd* tw2f, const cd* tw2i, const cd* __restrict__ tw3f,
-                                               const cd* __restrict__ tw3i, const cd* __restrict__ bhat, int tid) {
-  constexpr int L = R1 * R2 * R3, HALF = 128;
+__device__ __forceinline__ void rader_convolve(const PlainTile& tile, const cd* __restrict__ bhat, int tid) {
+  using AX = Axes<R1, R2, R3>;
+  constexpr int L = AX::L, HALF = 128;
+  static_assert(L / R1 <= HALF && L / R2 <= HALF && L / R3 <= HALF, "one butterfly per lane and stage");
   const int t = tid >> 7, i = tid & (HALF - 1);               // stage work item: tile, butterfly
-  const int is = i < L / R3 ? i : 0;                          // this lane's butterfly of the radix-R3 stages
-  // (the radix-R1 stages have 2 L / R1 = 180 butterflies: packed onto the first three wavefronts, the fourth only waits)
-  const int t1 = tid / (L / R1), i1 = tid % (L / R1);
-  const bool on1 = tid < 2 * (L / R1);
   {
     cd v[R2];
-    const bool on = i < L / R2;
-    if (on) mr_load<L, R2, R1, false>(tile, tw2f, t, i, v);
-    __syncthreads();
-    if (on) mr_store<L, R2, R1>(tile, t, i, v);
+    if (i < L / R2) {
+      axis_load<R2>(tile, t, AX::base2(i), AX::kStride2, v);
+      dft_sym<R2, false>(v);
+      axis_store<R2>(tile, t, AX::base2(i), AX::kStride2, v);
+    }
     __syncthreads();
   }
-  // seam: last forward stage (radix R3, outputs i + (L/R3) r), product with the kernel spectrum, first inverse
-  // stage (radix R3 of the order R3, R2, R1: the same L/R3-strided set of points)
   {
     cd v[R3];
-    const bool on = i < L / R3;
-    if (on) {
-      cd f[R3];                                               // (loaded here, not ahead: three wavefronts per SIMD hide the
-#pragma unroll                                                //  latency better than 116 more registers would)
-      for (int r = 1; r < R3; ++r) f[r] = tw3f[(r - 1) * (R1 * R2) + is];
-      mr_load_with<L, R3, false>(tile, t, i, v, f);
+    if (i < L / R3) {
+      const int base = AX::base3(i);
+      axis_load<R3>(tile, t, base, AX::kStride3, v);
+      dft_sym<R3, false>(v);
 #pragma unroll
-      for (int r = 0; r < R3; ++r) v[r] = cmul(v[r], bhat[is + (L / R3) * r]);
+      for (int r = 0; r < R3; ++r) v[r] = cmul(v[r], bhat[base + r * AX::kStride3]);
       dft_sym<R3, true>(v);
+      axis_store<R3>(tile, t, base, AX::kStride3, v);
     }
-    __syncthreads();
-    if (on) mr_store<L, R3, 1>(tile, t, i, v);
     __syncthreads();
   }
   {
     cd v[R2];
-    const bool on = i < L / R2;
-    if (on) mr_load<L, R2, R3, true>(tile, tw2i, t, i, v);
-    __syncthreads();
-    if (on) mr_store<L, R2, R3>(tile, t, i, v);
+    if (i < L / R2) {
+      axis_load<R2>(tile, t, AX::base2(i), AX::kStride2, v);
+      dft_sym<R2, true>(v);
+      axis_store<R2>(tile, t, AX::base2(i), AX::kStride2, v);
+    }
     __syncthreads();
   }
   {
+    // (the radix-R1 stages have 2 L / R1 = 180 butterflies: packed onto the first three wavefronts, the fourth only waits)
+    const int t1 = tid / (L / R1), i1 = tid % (L / R1);
     cd v[R1];
-    if (on1) {
-      cd f[R1];
-#pragma unroll
-      for (int r = 1; r < R1; ++r) f[r] = tw3i[(r - 1) * (R3 * R2) + i1];
-      mr_load_with<L, R1, true>(tile, t1, i1, v, f);
+    if (tid < 2 * (L / R1)) {
+      axis_load<R1>(tile, t1, AX::base1(i1), AX::kStride1, v);
+      dft_sym<R1, true>(v);
+      axis_store<R1>(tile, t1, AX::base1(i1), AX::kStride1, v);
     }
-    __syncthreads();
-    if (on1) mr_store<L, R1, R3 * R2>(tile, t1, i1, v);
     __syncthreads();
   }
 }
@@ -104,8 +96,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   constexpr int L = R1 * R2 * R3, HALF = 128;
   static_assert(L / R1 <= HALF && L / R2 <= HALF && L / R3 <= HALF, "one butterfly per lane and stage");
   __shared__ cd data[2 * L];
-  __shared__ cd tw2f[(R2 - 1) * R1];
-  __shared__ cd tw2i[(R2 - 1) * R3];
   __shared__ cd part[4][2];            // per wavefront: sum of the tile-0 / tile-1 inputs
   __shared__ cd dc[2];                 // x[0] of both tiles
   const int tid = threadIdx.x;
@@ -120,9 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   };
   stamp();
 
-  // ---- tables of the later stages, then the first forward stage straight from global memory
-  for (int k = tid; k < (R2 - 1) * R1; k += 256) tw2f[k] = a.tw2f[k];
-  for (int k = tid; k < (R2 - 1) * R3; k += 256) tw2i[k] = a.tw2i[k];
+  // ---- the first forward stage straight from global memory
   const auto* qp = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.quad)) + 4 * g;
   const int4 q = make_int4(qp[0], qp[1], qp[2], qp[3]);
   const size_t mic = size_t(a.NR) * N2, off = size_t(k1) * N2;
@@ -170,7 +158,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     }
     if ((tid & 63) == 0) { part[tid >> 6][0] = sx; part[tid >> 6][1] = sz; }
     dft_sym<R1, false>(v);
-    if (bf < NB1) mr_store<L, R1, 1>(tile, upper, bf, v);
+    if (bf < NB1) axis_store<R1>(tile, upper, Axes<R1, R2, R3>::base1(bf), Axes<R1, R2, R3>::kStride1, v);   // in place
   } else if (tid == 192) {                                    // bin 0 (the row's last position) bypasses the convolution
     const cd r1 = whiten(sa[L], sb[L]);
     const cd r2 = cscale(whiten(sc[L], sd[L]), keep2);
@@ -181,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   __syncthreads();
   stamp();
 
-  rader_convolve<R1, R2, R3>(tile, tw2f, tw2i, a.tw3f, a.tw3i, a.bhat, tid);
+  rader_convolve<R1, R2, R3>(tile, a.bhat, tid);
   stamp();
   // ---- epilogue: X[e] = x[0] + C[log_g e] (X[0] = sum of the inputs), column twiddle, store
   const cd x0 = cscale(dc[0], a.scale), z0 = cscale(dc[1], a.scale);

@@ -180,56 +180,55 @@ template <int LM> static int run_conv() {
   return bad;
 }
 
-// ---- mixed-radix stages of the Rader row pass: a 990-point transform as radix 11, 9, 10 (forward order) and as
-// radix 10, 9, 11 (the order of the inverse pass), both directions, two sub-transforms, against the naive DFT
-template <int N, int R, int P> static void make_mr_tw(std::vector<cd>& tw) {   // exp(-2 pi i k r / (P R)), [(r-1) P + k]
-  tw.assign(size_t(R - 1) * P, mk(0, 0));
-  for (int r = 1; r < R; ++r)
-    for (int k = 0; k < P; ++k) {
-      const long double a = -2.0L * M_PIl * (long double)(k * r) / (long double)(P * R);
-      tw[size_t(r - 1) * P + k] = mk(double(cosl(a)), double(sinl(a)));
-    }
+// ---- prime-factor stages of the Rader row pass (mixed_radix.h): the 990-point cyclic convolution as a 3-D convolution
+// in the residues mod 9, 10, 11 - forward DFTs along the three axes, product with the 3-D spectrum of the kernel,
+// inverse DFTs - against the direct O(L^2) sum
+template <int R, bool INV, class AX> static void emu_axis(std::vector<cd>& data, int which) {
+  const PlainTile tile{data.data(), AX::L};
+  const int nb = AX::L / R;
+  for (int j = 0; j < nb; ++j) {
+    const int base = which == 1 ? AX::base1(j) : (which == 2 ? AX::base2(j) : AX::base3(j));
+    const int stride = which == 1 ? AX::kStride1 : (which == 2 ? AX::kStride2 : AX::kStride3);
+    cd v[R];
+    axis_load<R>(tile, 0, base, stride, v);
+    dft_sym<R, INV>(v);
+    axis_store<R>(tile, 0, base, stride, v);
+  }
 }
 
-template <int N, int R, int P, bool INV> static void emu_mr_stage(std::vector<cd>& data, int tiles) {
-  std::vector<cd> tw;
-  make_mr_tw<N, R, P>(tw);
-  const PlainTile tile{data.data(), N};
-  constexpr int NB = N / R;
-  std::vector<cd> regs(size_t(tiles) * NB * R);
-  for (int t = 0; t < tiles; ++t)
-    for (int i = 0; i < NB; ++i) mr_load<N, R, P, INV>(tile, tw.data(), t, i, &regs[(size_t(t) * NB + i) * R]);
-  for (int t = 0; t < tiles; ++t)
-    for (int i = 0; i < NB; ++i) mr_store<N, R, P>(tile, t, i, &regs[(size_t(t) * NB + i) * R]);
-}
-
-template <int R1, int R2, int R3, bool INV> static double check_mr() {
-  constexpr int N = R1 * R2 * R3;
-  std::vector<cd> data(2 * N), plain(2 * N);
-  for (auto& v : data) v = mk(drand48() - 0.5, drand48() - 0.5);
-  plain = data;
-  emu_mr_stage<N, R1, 1, INV>(data, 2);
-  emu_mr_stage<N, R2, R1, INV>(data, 2);
-  emu_mr_stage<N, R3, R1 * R2, INV>(data, 2);
+static int run_axes() {
+  using AX = Axes<11, 9, 10>;
+  constexpr int L = AX::L;
+  std::vector<cd> a(L), b(L), A(L), B(L);
+  for (int s = 0; s < L; ++s) { a[s] = mk(drand48() - 0.5, drand48() - 0.5); b[s] = mk(drand48() - 0.5, drand48() - 0.5); }
+  int seen = 0;
+  std::vector<int> hit(L, 0);
+  for (int s = 0; s < L; ++s) { A[AX::pos(s)] = a[s]; B[AX::pos(s)] = b[s]; seen += !hit[AX::pos(s)]++; }
+  emu_axis<11, false, AX>(A, 1); emu_axis<9, false, AX>(A, 2); emu_axis<10, false, AX>(A, 3);
+  emu_axis<11, false, AX>(B, 1); emu_axis<9, false, AX>(B, 2); emu_axis<10, false, AX>(B, 3);
+  for (int p = 0; p < L; ++p) A[p] = cmul(A[p], B[p]);
+  emu_axis<10, true, AX>(A, 3); emu_axis<9, true, AX>(A, 2); emu_axis<11, true, AX>(A, 1);
   double worst = 0;
-  for (int t = 0; t < 2; ++t)
-    for (int o = 0; o < N; o += 7) worst = std::fmax(worst, naive_err(plain, size_t(t) * N, N, o, INV, data[size_t(t) * N + o]));
-  return worst / std::sqrt(double(N));
-}
-
-static int run_mixed() {
-  const double e[4] = {check_mr<11, 9, 10, false>(), check_mr<11, 9, 10, true>(), check_mr<10, 9, 11, false>(),
-                       check_mr<10, 9, 11, true>()};
-  int bad = 0;
-  for (int i = 0; i < 4; ++i) bad += !(e[i] < 1e-14);
-  std::printf("N=  990 mixed radix 11.9.10 fwd %.2e inv %.2e | 10.9.11 fwd %.2e inv %.2e %s\n", e[0], e[1], e[2], e[3], bad ? "FAIL" : "ok");
+  for (int s = 0; s < L; s += 3) {
+    long double cx = 0, cy = 0;
+    for (int q = 0; q < L; ++q) {
+      const cd x = a[q], y = b[(s - q + L) % L];
+      cx += (long double)x.x * y.x - (long double)x.y * y.y;
+      cy += (long double)x.x * y.y + (long double)x.y * y.x;
+    }
+    const cd got = A[AX::pos(s)];
+    worst = std::fmax(worst, std::hypot(got.x / L - double(cx), got.y / L - double(cy)));
+  }
+  const int bad = !(seen == L && worst < 1e-13);
+  std::printf("L=  990 cyclic convolution by prime-factor stages 11 x 9 x 10 (positions distinct: %d) err %.2e %s\n", seen, worst,
+              bad ? "FAIL" : "ok");
   return bad;
 }
 
 int main() {
   srand48(12345);
   int bad = 0;
-  bad += run_mixed();
+  bad += run_axes();
   bad += run_conv<10>();
   bad += run_conv<11>();
   bad += run_conv<12>();

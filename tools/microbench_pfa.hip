@@ -387,7 +387,7 @@ int main(int argc, char** argv) {
     for (cd* p : {bhat, t2f, t2i, t3f, t3i}) CHECK(hipMemcpy(p, rnd.data(), sizeof(cd) * 1024, hipMemcpyHostToDevice));
     unsigned long long* st;
     CHECK(hipMalloc(&st, sizeof(unsigned long long) * 8 * grid));
-    PfaRaderArgs ra{SP, quad, Y, bhat, r1, t2f, t2i, t3f, t3i, ridx, rowtab, N1, N2, NR, G, 1.0f / float(N1), 1.0 / double(n), nullptr};
+    PfaRaderArgs ra{SP, quad, Y, bhat, r1, ridx, rowtab, N1, N2, NR, G, 1.0f / float(N1), 1.0 / double(n), nullptr};
     time_it("rows (Rader 11 x 9 x 10): product", 20, [&] { k_pfa_rows_rader<11, 9, 10><<<dim3(grid), dim3(256)>>>(ra); });
     ra_keep = ra;
     ra.stamps = st;
