@@ -3,19 +3,20 @@
 // k_pfa_rows (pfa_kernels.h) computes the N2-point DFTs as chirp convolutions of 2^lm >= 2 N2 - 1 points.  When N2
 // is prime, Rader's re-indexing with a primitive root g of N2,
 //     X[g^r] = x[0] + sum_q x[g^-q] w^(g^(r-q)),      X[0] = sum_k x[k],
-// makes the same DFT a CYCLIC convolution of length L = N2 - 1, and for N2 = 991 that length is 990 = 11 x 9 x 10:
-// two mixed-radix transforms of 990 points (mixed_radix.h) instead of two of 2048, no chirp multiplications, and
-// 35 KB of LDS per workgroup instead of 68.  The rest is the row pass of pfa.hip unchanged: one workgroup per row
-// pair (k1, N1 - k1) of one packed transform, whitened pair spectra built on the fly, tile 1 = the reversed row,
-// column twiddle on the way out, Y[row][m2] to global memory.
+// makes the same DFT a CYCLIC convolution of length L = N2 - 1, and for N2 = 991 that length is 990 = 11 x 9 x 10 with
+// pairwise coprime factors: in the residues (s mod 9, s mod 10, s mod 11) the convolution is three-dimensional, and the
+// transforms around the pointwise product are plain 9-, 10- and 11-point DFTs along one axis each - in place, no
+// twiddle factors, no chirp multiplications (mixed_radix.h).  35 KB of LDS per workgroup instead of 68.  The rest is
+// the row pass of pfa.hip unchanged: one workgroup per row pair (k1, N1 - k1) of one packed transform, whitened pair
+// spectra built on the fly, tile 1 = the reversed row, column twiddle on the way out, Y[row][m2] to global memory.
 //
-//   forward    the rows of SP are stored in generator order (position q(e) = -log_g e, bin 0 last: the forward
-//              transform's storer writes them that way), so the radix-11 stage reads its inputs coalesced from
-//              global memory: the two halves of a wavefront own butterfly i of tile 0 and of tile 1, each half
-//              whitens six of the eleven (shared) inputs and the halves trade with v_permlane32_swap;
-//              radix 9 (LDS), then the seam: radix 10, x FFT(w^(g^s)) / (L n), inverse radix 10
-//   inverse    radix 9, 11 (order 10, 9, 11 so that the seam's two butterflies coincide); C[r] lands in LDS
-//   epilogue   four bins per lane: X[e] = x[0] + C[log_g e], column twiddle, coalesced stores
+//   forward    the rows of SP are stored in generator order at their prime-factor positions (x[g^-s] at pos(s), bin 0
+//              last: the forward transform writes them that way), so the stage along the 11-axis reads its inputs
+//              coalesced from global memory: the two halves of a wavefront own butterfly i of tile 0 and of tile 1,
+//              each half whitens six of the eleven (shared) inputs and the halves trade with v_permlane32_swap;
+//              9-axis (LDS), then the seam along the 10-axis: DFT, x the kernel's 3-D spectrum / (L n), inverse DFT
+//   inverse    9-axis, 11-axis; C[s] lands at pos(s)
+//   epilogue   four bins per lane: X[e] = x[0] + C[log_g e] through a position table, column twiddle, coalesced stores
 #pragma once
 #include "conv_kernels.h"
 #include "mixed_radix.h"
