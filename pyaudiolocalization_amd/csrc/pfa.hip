@@ -9,9 +9,10 @@
 //   c[m2 + N2 t] = 1/n  sum_k1 e^(2 pi i k1 t / N1) * e^(2 pi i u1 k1 m2 / N1) * sum_k2 e^(2 pi i u2 k2 m2 / N2) x[k1, k2]
 //                       '------ k_pfa_cols: dense N1-point DFT ------'   '------ k_pfa_rows: N2-point DFT + twiddle ------'
 //
-// (u1 = N2^-1 mod N1, u2 = N1^-1 mod N2).  The N2-point DFTs are chirp convolutions of length M = 2^lm >= 2 N2 - 1
-// that live entirely in LDS (forward FFT, multiply by the chirp spectrum, inverse FFT - two 2048-point tiles per
-// workgroup), and the N1-point DFTs are real cos / sin contractions whose coefficients are wave-uniform and
+// (u1 = N2^-1 mod N1, u2 = N1^-1 mod N2).  The N2-point DFTs are convolutions that live entirely in LDS - Rader's cyclic
+// convolution of N2 - 1 points where N2 = 991 (pfa_rader.h: 990 = 9 x 10 x 11, twiddle-free prime-factor stages), else a
+// chirp convolution of length M = 2^lm >= 2 N2 - 1 (pfa_kernels.h: forward FFT, multiply by the chirp spectrum, inverse
+// FFT, two tiles per workgroup) - and the N1-point DFTs are real cos / sin contractions whose coefficients are wave-uniform and
 // come through the scalar cache.  A transform touches HBM twice (16 B/point each way) instead of three times
 // at twice the points, and the output index m = m2 + N2 t is the natural one, so the correlation rows are
 // written in coalesced runs.
@@ -19,7 +20,8 @@
 // As in bluestein.hip one complex transform carries two mic pairs (real part = pair p, imaginary part = pair q)
 // and the whitened cross spectrum R = S_a conj(S_b) / (|.| + 1e-10) (utils.py:116-117) is built inside the
 // first FFT stage.  The mic spectra arrive in the permuted layout SP[mic][k1][k2], k1 <= (N1-1)/2 (written by the
-// forward transform's storer, bluestein.hip PermSpectrumStorer): row N1-k1
+// forward transform: pfa_forward.h for Rader rows - the same cut, transposed - or the storer of the four-step route,
+// bluestein.hip PermSpectrumStorer): row N1-k1
 // is row k1 reversed and conjugated (Hermitian symmetry), so one workgroup serves both rows from the same
 // loads - tile 0 transforms x[k1, e], tile 1 the reversed row z[e] = x[N1-k1, -e], whose DFT is the reversed DFT.
 #include <cmath>
