@@ -82,8 +82,8 @@ struct Engine {
   hipStream_t stream3 = nullptr;   // third launch-group slot (PAL_OVERLAP=3)
   hipEvent_t ev_join3 = nullptr;
   hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams
-  int overlap = 1;                 // PAL_OVERLAP: 0 one stream; 1 launch groups alternate between the two streams;
-                                   // 2 transforms on `stream`, peak selection on `stream2`; 3 groups rotate over three streams
+  int overlap = 3;                 // PAL_OVERLAP: 0 one stream; 1 launch groups alternate between two streams; 2 transforms on
+                                   // `stream`, peak selection on `stream2`; 3 (default) groups rotate over three streams
   bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
   bool allow_pfa = true;           // PAL_PFA=0 keeps the PHAT inverse on the four-step chirp convolution
   bool allow_rader = true;         // PAL_RADER=0 keeps the row pass on the in-LDS chirp convolution

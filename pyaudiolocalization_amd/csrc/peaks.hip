@@ -78,6 +78,8 @@ struct Shared {                          // pivot and finish kernels
   int flag;
   double bc_d[4];
   int bc_i[4];
+  int sel_pos[PAL_MAX_PEAKS];            // selected peaks of the finish launch (written and read by lane 0)
+  double sel_h[PAL_MAX_PEAKS];
 };
 
 struct StreamWave {                      // one wavefront's share of a segment's statistics
@@ -432,7 +434,7 @@ __device__ __forceinline__ bool next_candidate(const SelArgs a, const double* c,
 
 // top-num_peaks kept peaks >= thr in the window; returns count or -1 on overflow
 __device__ __forceinline__ int select_peaks(const SelArgs a, const double* c, int tid, Shared& s, double thr, bool windowed, int wlo,
-                            int whi, double first_h, int first_m, int* sel, double* selh) {
+                            int whi, double first_h, int first_m) {
   if (tid == 0) s.memo_n = 0;
   __syncthreads();
   double bound_h = INFINITY;
@@ -449,7 +451,10 @@ __device__ __forceinline__ int select_peaks(const SelArgs a, const double* c, in
     }
     const int st = resolve(c, a.n, a.dist, tid, s, cm, ch);
     if (st < 0) return -1;
-    if (st == 1) { sel[count] = cm; selh[count] = ch; ++count; }
+    if (st == 1) {                                             // (the list lives in LDS: 48 registers per lane otherwise)
+      if (tid == 0) { s.sel_pos[count] = cm; s.sel_h[count] = ch; }
+      ++count;
+    }
     bound_h = ch;
     bound_m = cm;
   }
@@ -1012,8 +1017,6 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   stamp();
   // ---- fallback chain (utils.py:152-179) ----
   int branch = 0;
-  int sel[PAL_MAX_PEAKS];
-  double selh[PAL_MAX_PEAKS];
   int count = 0;
   bool overflow = false;
   const bool windowed = !isnan(a.med);
@@ -1035,31 +1038,34 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   if (!argmax_fallback) {
     const bool first_ok = !windowed;                       // unwindowed: the best peak is already known
     const SelArgs sa{n, a.n2, a.dist, a.num_peaks, a.fs, a.med};
-    count = select_peaks(sa, c, tid, s, thr, windowed, wlo, whi, first_ok ? hb : 0.0, first_ok ? mb : -1, sel, selh);
+    count = select_peaks(sa, c, tid, s, thr, windowed, wlo, whi, first_ok ? hb : 0.0, first_ok ? mb : -1);
     if (count < 0) overflow = true;
     if (count == 0 && windowed) {
       branch |= PAL_BR_WINDOW_RETRY;
-      count = select_peaks(sa, c, tid, s, mean_abs, true, wlo, whi, 0.0, -1, sel, selh);
+      count = select_peaks(sa, c, tid, s, mean_abs, true, wlo, whi, 0.0, -1);
       if (count < 0) overflow = true;
       if (count == 0) { branch |= PAL_BR_ARGMAX_WINDOW; argmax_fallback = true; }
     }
   }
-  if (argmax_fallback || overflow) { sel[0] = imax; selh[0] = vmax; count = 1; }
+  if (argmax_fallback || overflow) {
+    if (tid == 0) { s.sel_pos[0] = imax; s.sel_h[0] = vmax; }
+    count = 1;
+  }
   stamp();
 
   if (tid == 0) {
     pal_pair_record r;
-    r.k_sel = sel[0];
+    r.k_sel = s.sel_pos[0];
     r.branch = branch;
     r.k_argmax = imax;
     r.n_sel = count;
     r.cmax = vmax;
     r.cmin = vmin;
     r.snr = snr;
-    r.sel_height = selh[0];
+    r.sel_height = s.sel_h[0];
     table[row] = r;
     if (ksel_multi)
-      for (int k = 0; k < PAL_MAX_PEAKS; ++k) ksel_multi[size_t(row) * PAL_MAX_PEAKS + k] = k < count ? sel[k] : -1;
+      for (int k = 0; k < PAL_MAX_PEAKS; ++k) ksel_multi[size_t(row) * PAL_MAX_PEAKS + k] = k < count ? s.sel_pos[k] : -1;
     if (overflow) atomicOr(status, 1);
   }
 }
