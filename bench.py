@@ -153,7 +153,7 @@ def main() -> None:
     # beside the other stream's FFT passes and its elapsed time stretches severalfold, so elapsed totals do not rank the
     # kernels by work.  One untimed calibration frame on a second, single-stream engine (PAL_OVERLAP=0, events around
     # every launch) ranks them by their time alone; the roofline then uses THAT kernel's live duration from the timed run.
-    alone = {}
+    alone, alone_avg = {}, {}
     if rank == 0 and entries:
         saved = os.environ.get("PAL_OVERLAP")
         os.environ["PAL_OVERLAP"] = "0"
@@ -173,6 +173,7 @@ def main() -> None:
             cal.synchronize()
             cal.profile_end()
             alone = {k: v[0] for k, v in cal.profile_entries().items() if v[1] > 0}
+            alone_avg = {k: v[0] / v[1] for k, v in cal.profile_entries().items() if v[1] > 0}
         finally:
             cal.close()
     ranked = [k for k in sorted(alone, key=alone.get, reverse=True) if k in entries and entries[k][1] > 0]
@@ -200,6 +201,12 @@ def main() -> None:
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": dom_launches,
                     "event_sampling": f"every {args.event_every}th launch group",
                     "dominant_by": "largest time alone (one serial calibration frame)" if ranked else "largest elapsed time",
+                    # the same launch alone on the GPU (calibration frame, launch groups of 256 transforms): what the kernel
+                    # itself reaches; `frac` above is measured while two other launch groups share the CUs
+                    "alone_launch_us": round(alone_avg[dom_name] * 1e3, 2) if dom_name in alone_avg else None,
+                    "frac_alone": (round(b_alg * min(pairs_per_launch, pairs / max(1, -(-((pairs + 1) // 2) // chunk)))
+                                         / (alone_avg[dom_name] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                   if dom_name in alone_avg else None),
                     "algorithmic_bytes_per_pair": round(b_alg, 1),
                     "pairs_per_launch": round(pairs_per_launch, 2)}
 
