@@ -77,7 +77,7 @@ void pal_destroy(pal_handle h);
 const char* pal_last_error(pal_handle h); /* h may be NULL: error of the last failed pal_create */
 int pal_synchronize(pal_handle h);
 /* transforms processed per launch group (workspace = chunk * M * 16 B); 0 keeps the default: 128, and for the pair
- * pipeline (two pairs per transform) 256 where one workspace slot stays below 1 GiB, 32 at least */
+ * pipeline (two pairs per transform) 240 where one workspace slot stays below 1 GiB, 32 at least */
 int pal_set_chunk(pal_handle h, int chunk);
 /* packed transforms (pairs / 2) one launch group of the all-pairs pipeline carries for frames of L samples */
 int pal_pair_group_size(pal_handle h, int L, int32_t* transforms);

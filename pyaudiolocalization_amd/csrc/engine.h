@@ -90,11 +90,13 @@ struct Engine {
   int pfa_sub = 0;                 // transforms per row/column pass of the prime-factor route (PAL_PFA_SUB; 0 = whole group)
   std::string err;
   int chunk = 128;                              // transforms per launch group (forward spectra, simulation, synchronisation)
-  bool chunk_auto = true;                       // pair pipeline: 256 transforms per group where a workspace slot stays <= 1 GiB
+  bool chunk_auto = true;                       // pair pipeline: 240 transforms per group where a workspace slot stays <= 1 GiB
+                                                // (480 rows: the finish launch's workgroups, two per CU, leave slots free
+                                                //  beside the other streams' launches - 256 measured 3 % less than 240)
   int pair_group(int n) const {                 // (PAL_CHUNK / pal_set_chunk fix both)
     if (!chunk_auto) return chunk;
     const long long g = (1ll << 30) / (16ll * (n > 0 ? n : 1));
-    return int(g < 32 ? 32 : (g > 256 ? 256 : g));
+    return int(g < 32 ? 32 : (g > 240 ? 240 : g));
   }
   std::map<std::tuple<int, int, int>, Plan> plans;   // (n, lin, nout) -> plan
   cd* stage_tw[13] = {};                        // stage-major twiddles per log2 N
