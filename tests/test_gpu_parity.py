@@ -348,6 +348,21 @@ def test_pair_list_and_bootstrap(engine):
     assert set(m) == {"peak_to_peak_ratio", "snr", "significant"} and bool(m["significant"]) is True
 
 
+def test_pair_group_size_rule(engine):
+    """Launch groups of the pair pipeline: 240 packed transforms where a workspace slot stays under 1 GiB, at least 32;
+    pal_set_chunk (or PAL_CHUNK) fixes the size."""
+    from pyaudiolocalization_amd import Engine
+    fresh = Engine(engine.device)
+    try:
+        assert fresh.pair_group_size(44100) == 240
+        assert fresh.pair_group_size(200000) == (1 << 30) // (16 * 399999)
+        assert fresh.pair_group_size(1 << 20) == 32
+        fresh.set_chunk(7)
+        assert fresh.pair_group_size(44100) == 7
+    finally:
+        fresh.close()
+
+
 def test_chunk_size_does_not_change_results(engine):
     frames = np.random.default_rng(4).standard_normal((2, 6, 1500))
     engine.set_chunk(32)
