@@ -7,6 +7,8 @@ working.  Citations are file:line into the reference.
 """
 from __future__ import annotations
 
+import logging
+
 import numpy as np
 
 from .engine import default_engine
@@ -79,9 +81,18 @@ def dynamic_range_compression_soft_clip(signal: np.ndarray, threshold: float = 0
 
 
 def resample_audio(data: np.ndarray, original_fs: float, target_fs: float) -> np.ndarray:
-    """Real-audio ingest is outside the hot path; needs the optional resampy package."""
-    import resampy  # noqa: PLC0415 - optional, absent in the build image
-    return resampy.resample(data, original_fs, target_fs, filter="kaiser_best")
+    """signal_processing.py:105-107 (outside the hot path): resampy's kaiser_best when that optional package
+    is installed.  Without it (the build image): SciPy's polyphase resampler with a Kaiser window - band-limited to the
+    same purpose but NOT sample-identical to resampy (parity unpinned: no resampy output exists here to compare with)."""
+    try:
+        import resampy  # noqa: PLC0415 - optional dependency
+        return resampy.resample(data, original_fs, target_fs, filter="kaiser_best")
+    except ImportError:
+        from fractions import Fraction  # noqa: PLC0415
+        from scipy.signal import resample_poly  # noqa: PLC0415
+        logging.getLogger(__name__).warning("resampy is not installed: resampling with scipy.signal.resample_poly (Kaiser window)")
+        ratio = Fraction(float(target_fs) / float(original_fs)).limit_denominator(1000)
+        return resample_poly(np.asarray(data, dtype=np.float64), ratio.numerator, ratio.denominator, window=("kaiser", 14.769656459379492))
 
 
 def _filter_design(fs: float, method: str, lowcut: float, highcut: float, filter_order: int):

@@ -296,9 +296,32 @@ def synchronize_signals_improved(signals: List[np.ndarray], fs: float, use_inter
     return [np.pad(p, (0, length - len(p))) for p in padded]
 
 
+def _read_wav_pcm(path: str) -> Tuple[np.ndarray, int]:
+    """PCM WAV through the standard library, scaled like ``soundfile.read`` scales integer PCM (x / 2^(bits-1); 8-bit is
+    unsigned): the fallback of read_audio_files when the optional soundfile package is absent.  [frames] or [frames][ch]."""
+    import wave  # noqa: PLC0415
+    with wave.open(path, "rb") as w:
+        channels, width, fs, frames = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(frames)
+    if width == 1:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float64) - 128.0) / 128.0
+    elif width == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float64) / 32768.0
+    elif width == 3:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        x = np.where(v >= 1 << 23, v - (1 << 24), v).astype(np.float64) / float(1 << 23)
+    elif width == 4:
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float64) / float(1 << 31)
+    else:
+        raise ValueError(f"unsupported PCM sample width {width}")
+    return (x.reshape(-1, channels) if channels > 1 else x), fs
+
+
 def read_audio_files(audio_files: List[str], expected_fs: float) -> List[np.ndarray]:
-    """Real-audio ingest (utils.py:459-482): outside the hot path; needs the optional
-    soundfile / resampy packages, which the build image does not have."""
+    """Real-audio ingest (utils.py:459-482; SURVEY 8f N4, outside the hot path): mono mix, resample to `expected_fs`,
+    normalise, compress.  Decoding uses the optional soundfile package when it is installed and the standard library's
+    PCM WAV reader otherwise (the build image has neither soundfile nor resampy)."""
     from .signal_processing import dynamic_range_compression, normalize_signal, resample_audio
     out = []
     for path in audio_files:
@@ -306,8 +329,11 @@ def read_audio_files(audio_files: List[str], expected_fs: float) -> List[np.ndar
             log.error("audio file not found: %s", path)
             raise FileNotFoundError(f"audio file not found: {path}")
         try:
-            import soundfile  # noqa: PLC0415 - optional dependency
-            data, fs = soundfile.read(path)
+            try:
+                import soundfile  # noqa: PLC0415 - optional dependency
+                data, fs = soundfile.read(path)
+            except ImportError:
+                data, fs = _read_wav_pcm(path)
             if data.ndim > 1:
                 data = np.mean(data, axis=1)
             if fs != expected_fs:

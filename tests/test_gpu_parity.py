@@ -536,6 +536,45 @@ def test_localize_sound_source_position(golden, tmp_path, monkeypatch):
         M.localize_sound_source({"fs": 48000}, show_plots=False)
 
 
+def test_real_audio_ingest_without_soundfile(engine, tmp_path):
+    """read_audio_files (utils.py:459-482) with the standard-library WAV decoder that stands in for the
+    absent soundfile package: PCM scaling x / 2^(bits-1), mono mix, normalise + compress like the oracle; a missing file
+    and an undecodable one raise what the reference raises."""
+    import wave
+    from pyaudiolocalization_amd import utils as U
+    rng = np.random.default_rng(12)
+    fs, n = 16000, 4000
+    paths, want = [], []
+    for k, (width, channels) in enumerate(((2, 1), (2, 2), (3, 1), (1, 1))):
+        x = rng.uniform(-0.9, 0.9, (n, channels))
+        if width == 2:
+            q = np.round(x * 32767).astype("<i2")
+            raw, dec = q.tobytes(), q.astype(np.float64) / 32768.0
+        elif width == 3:
+            q = np.round(x * (2 ** 23 - 1)).astype(np.int32)
+            b = (q & 0xFFFFFF).astype(np.uint32)
+            raw = np.stack([(b & 255), (b >> 8) & 255, (b >> 16) & 255], axis=-1).astype(np.uint8).tobytes()
+            dec = q.astype(np.float64) / float(2 ** 23)
+        else:
+            q = np.round(x * 127 + 128).astype(np.uint8)
+            raw, dec = q.tobytes(), (q.astype(np.float64) - 128.0) / 128.0
+        path = tmp_path / f"mic{k}.wav"
+        with wave.open(str(path), "wb") as w:
+            w.setnchannels(channels); w.setsampwidth(width); w.setframerate(fs); w.writeframes(raw)
+        paths.append(str(path))
+        mono = dec.mean(axis=1) if channels > 1 else dec[:, 0]
+        want.append(O.dynamic_range_compression(O.normalize_signal(mono)))
+    got = U.read_audio_files(paths, fs)
+    for g, w_ in zip(got, want):
+        assert g.shape == w_.shape and np.max(np.abs(g - w_)) <= 1e-15
+    with pytest.raises(FileNotFoundError):
+        U.read_audio_files([str(tmp_path / "absent.wav")], fs)
+    bad = tmp_path / "bad.wav"
+    bad.write_bytes(b"not a wave file")
+    with pytest.raises(RuntimeError):
+        U.read_audio_files([str(bad)], fs)
+
+
 def test_profile_counters_and_plan(engine):
     info = engine.plan_info(44100)
     assert info["n"] == 88199 and info["conv_len"] in (196608, 262144) and info["m1"] * info["m2"] == info["conv_len"]
