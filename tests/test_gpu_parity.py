@@ -575,6 +575,40 @@ def test_real_audio_ingest_without_soundfile(engine, tmp_path):
         U.read_audio_files([str(bad)], fs)
 
 
+def test_localize_from_audio_files(engine, tmp_path):
+    """main.py:176-186: the real-recordings branch (use_simulation=False) end to end on WAV files of one noise burst with
+    geometric delays: the result dict has the reference's keys and a finite position inside the solver's bounds.  (No
+    accuracy claim: like the reference, the pipeline synchronises the recordings first, utils.py:407-457, which removes
+    delays below 50 ms - the stage-by-stage tests pin every stage against the oracle instead.)"""
+    import wave
+    import pyaudiolocalization_amd.main as M
+    fs, n = 16000, 8000
+    mics = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0.5]], dtype=float)
+    src = np.array([0.4, 0.7, 0.3])
+    c = M.speed_of_sound(20.0, 50.0)
+    rng = np.random.default_rng(33)
+    base = rng.standard_normal(n + 400)
+    paths = []
+    for k, mpos in enumerate(mics):
+        d = int(round(np.linalg.norm(src - mpos) / c * fs))
+        x = base[200 - d: 200 - d + n] * 0.2
+        q = np.round(x / np.max(np.abs(x)) * 30000).astype("<i2")
+        path = tmp_path / f"m{k}.wav"
+        with wave.open(str(path), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(fs); w.writeframes(q.tobytes())
+        paths.append(str(path))
+    cfg = dict(M.config)
+    cfg.update({"fs": fs, "mic_positions": mics.tolist(), "source_position": None, "analyze_correlation": False,
+                "use_3d_plot": False, "max_expected_delay": 0.01})
+    res = M.localize_sound_source(cfg, audio_files=paths, use_simulation=False, show_plots=False)
+    assert set(res) >= {"estimated_position", "actual_position", "mic_positions", "correlation_metrics", "correlation_matrix",
+                        "calibration_data"}
+    assert res["actual_position"] is None
+    pos = np.asarray(res["estimated_position"], dtype=float)
+    assert pos.shape == (3,) and np.all(np.isfinite(pos)) and np.all(np.abs(pos) < 10.0)
+    assert res["correlation_matrix"].shape == (5, 5)
+
+
 def test_profile_counters_and_plan(engine):
     info = engine.plan_info(44100)
     assert info["n"] == 88199 and info["conv_len"] in (196608, 262144) and info["m1"] * info["m2"] == info["conv_len"]
