@@ -117,7 +117,7 @@ template <int R1, int R2, int R3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_pfa_fwd_rows_rader(PfaFwdRowsArgs a) {
   constexpr int L = R1 * R2 * R3;
   __shared__ cd data[2 * L];
-  __shared__ cd part[4][2];            // per wavefront: sum of the tile-0 / tile-1 inputs
+  __shared__ cd total[2];              // sum of the tile-0 / tile-1 inputs behind column 0 (from the convolution's spectrum)
   __shared__ cd dc[2];                 // input column 0 of both tiles
   const int tid = threadIdx.x;
   const int g = blockIdx.x % a.G, k1 = blockIdx.x / a.G;
@@ -146,24 +146,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     v1[u] = y1[ee];
     qi[u] = a.qidx[ee];
   }
-  cd sx = mk(0, 0), sz = mk(0, 0);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int e = tid + 256 * u;
     const cd x = cmul(v0[u], a.r1[mod_n1(__umul24(uk0, unsigned(e)))]);      // e^{-2 pi i u1 k1 m2 / N1}
     const cd z = cmul(v1[u], a.r1[mod_n1(__umul24(uk1, unsigned(e)))]);
     if (e < N2) {
-      sx = sx + x;
-      sz = sz + z;
       if (e == 0) { dc[0] = x; dc[1] = z; }
       else { data[qi[u]] = x; data[L + qi[u]] = z; }
     }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    sx.x += __shfl_down(sx.x, o, 64); sx.y += __shfl_down(sx.y, o, 64);
-    sz.x += __shfl_down(sz.x, o, 64); sz.y += __shfl_down(sz.y, o, 64);
-  }
-  if ((tid & 63) == 0) { part[tid >> 6][0] = sx; part[tid >> 6][1] = sz; }
   __syncthreads();
   // ---- the cyclic convolution: first stage along axis R1 (in place), then the shared stages
   using AX = Axes<R1, R2, R3>;
@@ -177,13 +169,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     }
     __syncthreads();
   }
-  rader_convolve<R1, R2, R3>(tile, a.bhat, tid);
+  rader_convolve<R1, R2, R3>(tile, a.bhat, total, tid);
   // ---- epilogue: output position p = pos(q) holds bin k2 = g^-q: Z[k1, k2] = x[0] + C0[pos(-q)] and
   //      Z[N1 - k1, N2 - k2] = x'[0] + C1[pos(-q + L/2)] (-1 = g^(L/2)).  pos() is a ring isomorphism, so both are
   //      coordinate-wise: negate the residues, add L/2 mod (R2, R3, R1).  Separate the two frames, store coalesced.
   const cd x0 = dc[0], z0 = dc[1];
-  const cd sum0 = part[0][0] + part[1][0] + part[2][0] + part[3][0];
-  const cd sum1 = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+  const cd sum0 = total[0] + x0, sum1 = total[1] + z0;
   const bool second = 2 * g + 1 < a.rows;
   const size_t mic = size_t(a.NR) * N2;
   cd* Sa = a.SP + size_t(2 * g) * mic + size_t(k1) * N2;

@@ -42,8 +42,9 @@ struct PfaRaderArgs {
 // in prime-factor coordinates (mixed_radix.h) the convolution is three-dimensional and its stages are plain DFTs along
 // one axis each, in place and without twiddles: forward along R2, the seam along R3 (forward DFT, x the kernel's 3-D
 // spectrum `bhat`, inverse DFT on the same registers), inverse along R2 and R1.  One barrier per stage; ends with one.
+// `total[tile]` (LDS) receives the sum of the tile's inputs, which the spectrum holds at its origin.
 template <int R1, int R2, int R3>
-__device__ __forceinline__ void rader_convolve(const PlainTile& tile, const cd* __restrict__ bhat, int tid) {
+__device__ __forceinline__ void rader_convolve(const PlainTile& tile, const cd* __restrict__ bhat, cd* total, int tid) {
   using AX = Axes<R1, R2, R3>;
   constexpr int L = AX::L, HALF = 128;
   static_assert(L / R1 <= HALF && L / R2 <= HALF && L / R3 <= HALF, "one butterfly per lane and stage");
@@ -63,6 +64,7 @@ __device__ __forceinline__ void rader_convolve(const PlainTile& tile, const cd* 
       const int base = AX::base3(i);
       axis_load<R3>(tile, t, base, AX::kStride3, v);
       dft_sym<R3, false>(v);
+      if (i == 0) total[t] = v[0];                            // the 3-D spectrum at the origin = the sum of the tile's inputs
 #pragma unroll
       for (int r = 0; r < R3; ++r) v[r] = cmul(v[r], bhat[base + r * AX::kStride3]);
       dft_sym<R3, true>(v);
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   constexpr int L = R1 * R2 * R3, HALF = 128;
   static_assert(L / R1 <= HALF && L / R2 <= HALF && L / R3 <= HALF, "one butterfly per lane and stage");
   __shared__ cd data[2 * L];
-  __shared__ cd part[4][2];            // per wavefront: sum of the tile-0 / tile-1 inputs
+  __shared__ cd total[2];              // sum of the tile-0 / tile-1 inputs (from the convolution's spectrum)
   __shared__ cd dc[2];                 // x[0] of both tiles
   const int tid = threadIdx.x;
   const int g = blockIdx.x % a.G, k1 = blockIdx.x / a.G;
@@ -142,22 +144,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
       va[u] = sa[at]; vb[u] = sb[at]; vc[u] = sc[at]; vd[u] = sd[at];
     }
     cd v[2 * HR];
-    cd sx = mk(0, 0), sz = mk(0, 0);
 #pragma unroll
     for (int u = 0; u < HR; ++u) {
       const cd r1 = whiten(va[u], vb[u]);
       const cd r2 = cscale(whiten(vc[u], vd[u]), keep2);
       const cd x = mk(r1.x - r2.y, r1.y + r2.x), z = mk(r1.x + r2.y, r2.x - r1.y);
-      if (bf < NB1 && upper * HR + u < R1) { sx = sx + x; sz = sz + z; }
       // lower half: v[u] = own x, v[HR + u] = the upper half's x;  upper half: v[u] = the lower half's z, v[HR + u] = own z
       swap_pair(x.x, z.x, v[u].x, v[HR + u].x);
       swap_pair(x.y, z.y, v[u].y, v[HR + u].y);
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      sx.x += __shfl_down(sx.x, o, 64); sx.y += __shfl_down(sx.y, o, 64);
-      sz.x += __shfl_down(sz.x, o, 64); sz.y += __shfl_down(sz.y, o, 64);
-    }
-    if ((tid & 63) == 0) { part[tid >> 6][0] = sx; part[tid >> 6][1] = sz; }
     dft_sym<R1, false>(v);
     if (bf < NB1) axis_store<R1>(tile, upper, Axes<R1, R2, R3>::base1(bf), Axes<R1, R2, R3>::kStride1, v);   // in place
   } else if (tid == 192) {                                    // bin 0 (the row's last position) bypasses the convolution
@@ -165,17 +160,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     const cd r2 = cscale(whiten(sc[L], sd[L]), keep2);
     const cd x = mk(r1.x - r2.y, r1.y + r2.x), z = mk(r1.x + r2.y, r2.x - r1.y);
     dc[0] = x; dc[1] = z;
-    part[3][0] = x; part[3][1] = z;
   }
   __syncthreads();
   stamp();
 
-  rader_convolve<R1, R2, R3>(tile, a.bhat, tid);
+  rader_convolve<R1, R2, R3>(tile, a.bhat, total, tid);
   stamp();
   // ---- epilogue: X[e] = x[0] + C[log_g e] (X[0] = sum of the inputs), column twiddle, store
   const cd x0 = cscale(dc[0], a.scale), z0 = cscale(dc[1], a.scale);
-  const cd sum0 = cscale(part[0][0] + part[1][0] + part[2][0] + part[3][0], a.scale);
-  const cd sum1 = cscale(part[0][1] + part[1][1] + part[2][1] + part[3][1], a.scale);
+  const cd sum0 = cscale(total[0] + dc[0], a.scale), sum1 = cscale(total[1] + dc[1], a.scale);
   const int kr = k1 ? N1 - k1 : 0;
   const auto* rt0 = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.rowtab)) + 2 * k1;
   const auto* rt1 = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.rowtab)) + 2 * kr;
