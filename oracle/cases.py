@@ -165,3 +165,28 @@ def calibration_noise(cfg, seed):
     noise = np.array([np.random.normal(0, cfg["calibration"].get("noise_level", 0.01), size=n) for _ in cfg["mic_positions"]])
     np.random.set_state(state)
     return noise
+
+
+def loc_config(analyze: bool) -> dict:
+    """Small localisation case for the calibration correction and the per-pair metrics of main.py:147-157,209-222:
+    5 scattered microphones, chirp 300 -> 1500 Hz, 8 kHz x 0.25 s, no reflections (fast enough for the reference's
+    1000-shuffle bootstrap: 10 pairs x 1000 PHAT correlations of 4 k points)."""
+    rng = np.random.default_rng(31)
+    cfg = c1_config()
+    cfg.update({"fs": 8000, "duration": 0.25, "mic_positions": rng.uniform(-0.6, 0.6, (5, 3)).tolist(),
+                "source_position": [1.4, -0.8, 0.9], "signal_type": "chirp", "freq": 300, "reflective_planes": []})
+    cfg["localization"] = dict(cfg["localization"], analyze_correlation=bool(analyze), visualize_correlation=False)
+    return cfg
+
+
+LOC_CALIBRATION = [{"delay": d, "amplitude": 1.0} for d in (0.0, 2.5e-4, -1.25e-4, 3.75e-4, -5.0e-4)]
+LOC_SEED = 20240917          # np.random.seed right before localize_sound_source: the bootstrap shuffles use the global RNG
+
+
+def unequal_sync_signals():
+    """Recordings whose lengths differ by a few samples (what read_audio_files returns for real files): a common
+    noise burst at different offsets, 8 kHz."""
+    rng = np.random.default_rng(47)
+    y = rng.standard_normal(3300)
+    lens, offs = (3000, 2993, 3011, 2987, 3004), (120, 131, 117, 126, 139)
+    return [y[o: o + n] + 0.05 * rng.standard_normal(n) for n, o in zip(lens, offs)], 8000

@@ -81,7 +81,7 @@ def stage_outputs(signals, fs, meds, prefix=""):
     return out
 
 
-def run_localize(cfg, materials=None, base=None):
+def run_localize(cfg, materials=None, base=None, calibration=None, seed=None, full=False):
     """localize_sound_source in a scratch dir (it writes PNGs)."""
     keep_mat, keep_gen = ref_main.material_properties, ref_sp.generate_signal
     cwd = os.getcwd()
@@ -92,9 +92,11 @@ def run_localize(cfg, materials=None, base=None):
             ref_sp.generate_signal = lambda *a, **k: base.copy()
         with tempfile.TemporaryDirectory() as tmp:
             os.chdir(tmp)
-            res = ref_main.localize_sound_source(cfg, use_simulation=True, show_plots=False)
+            if seed is not None:
+                np.random.seed(seed)
+            res = ref_main.localize_sound_source(cfg, calibration_data=calibration, use_simulation=True, show_plots=False)
             os.chdir(cwd)
-        return np.asarray(res["estimated_position"], dtype=np.float64)
+        return res if full else np.asarray(res["estimated_position"], dtype=np.float64)
     finally:
         os.chdir(cwd)
         ref_main.material_properties, ref_sp.generate_signal = keep_mat, keep_gen
@@ -244,9 +246,38 @@ def golden_calibration():
     save("calibration.npz", **out)
 
 
+def golden_localize_extras():
+    """main.py:147-157,209-222: calibration correction and per-pair correlation metrics inside localize_sound_source
+    (global NumPy RNG seeded right before the call), and synchronize_signals_improved on unequal-length signals."""
+    out = {}
+    cfg = cases.loc_config(False)
+    sig = ref_main.simulate_signals_with_multipath(cfg["source_position"], np.array(cfg["mic_positions"]), cfg["fs"],
+                                                   cases.C_SOUND, cfg["duration"], "chirp", cfg["freq"], [],
+                                                   ref_main.material_properties, 3, 0.01)
+    out.update(stage_outputs(sig, cfg["fs"], (0.05,), prefix="loc_"))
+    out["loc_sim_digest"] = np.array([cases.waveform_digest(s) for s in sig])
+    out["loc_position_plain"] = run_localize(cfg)
+    out["loc_position_calib"] = run_localize(cfg, calibration=cases.LOC_CALIBRATION)
+    res = run_localize(cases.loc_config(True), calibration=cases.LOC_CALIBRATION, seed=cases.LOC_SEED, full=True)
+    out["loc_position_metrics"] = np.asarray(res["estimated_position"], dtype=np.float64)
+    keys = sorted(res["correlation_metrics"])
+    out["loc_metric_pairs"] = np.array(keys, dtype=np.int32)
+    out["loc_ptp"] = np.array([res["correlation_metrics"][k]["peak_to_peak_ratio"] for k in keys])
+    out["loc_snr"] = np.array([res["correlation_metrics"][k]["snr"] for k in keys])
+    out["loc_significant"] = np.array([bool(res["correlation_metrics"][k]["significant"]) for k in keys])
+    # mismatched calibration length: ignored with a warning (main.py:148-150) -> the plain position
+    out["loc_position_badcalib"] = run_localize(cfg, calibration=cases.LOC_CALIBRATION[:3])
+    sigs, fs = cases.unequal_sync_signals()
+    synced = ref_utils.synchronize_signals_improved(sigs, fs)
+    out["uneq_len"] = np.array([len(s) for s in synced])
+    out["uneq_digest"] = np.array([cases.waveform_digest(s) for s in synced])
+    out["uneq_first_nonzero"] = np.array([int(np.flatnonzero(s)[0]) for s in synced])
+    save("localize_extras.npz", **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["edges", "filters", "images", "c1", "c2", "metric", "c4", "c5", "c3", "calibration"]
-    table = {"calibration": golden_calibration, "edges": golden_selection_edges, "filters": golden_filters, "images": golden_images, "c1": golden_c1,
+    todo = sys.argv[1:] or ["edges", "filters", "images", "c1", "c2", "metric", "c4", "c5", "c3", "calibration", "extras"]
+    table = {"extras": golden_localize_extras, "calibration": golden_calibration, "edges": golden_selection_edges, "filters": golden_filters, "images": golden_images, "c1": golden_c1,
              "c2": golden_c2, "c3": golden_c3, "c4": golden_c4, "c5": golden_c5, "metric": golden_metric}
     for key in todo:
         t0 = time.time()

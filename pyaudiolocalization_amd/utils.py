@@ -263,35 +263,47 @@ def compute_weights(correlation_metrics, mic_pairs) -> np.ndarray:
 # ---------------------------------------------------------------- synchronisation (GPU correlations)
 def synchronize_signals_improved(signals: List[np.ndarray], fs: float, use_interpolation: bool = True) -> List[np.ndarray]:
     """Align every signal to the highest-energy one (utils.py:407-457).  The M full cross-correlations
-    and their argmax run on the engine; the 5-point spline refinement and zero padding are host work."""
+    and their argmax run on the engine; the 5-point spline refinement and zero padding are host work.
+
+    Signals of different lengths are accepted like in the reference (recordings read by read_audio_files seldom
+    agree to the sample): for the engine call only, every row is zero-padded at its end to the longest length
+    Lmax.  Trailing zeros leave correlate(sig, ref, 'full') unchanged lag by lag - index k of the reference's
+    sequence (length len(sig) + len(ref) - 1) sits at k + (Lmax - len(ref)) of the padded one - so the shift is
+    k' - (Lmax - 1), and the pads are applied to the ORIGINAL rows as utils.py:448-456 does."""
     from scipy.interpolate import CubicSpline
-    if len({len(s) for s in signals}) != 1:
-        raise ValueError("the engine synchronises equal-length signals (simulated frames always are)")
-    rows = np.asarray(signals, dtype=np.float64)
-    energies = [np.sum(np.asarray(s) ** 2) for s in signals]
+    sigs = [np.asarray(s, dtype=np.float64) for s in signals]
+    lens = [len(s) for s in sigs]
+    lmax = max(lens)
+    if len(set(lens)) == 1:
+        rows = np.asarray(sigs, dtype=np.float64)
+    else:
+        rows = np.zeros((len(sigs), lmax))
+        for r, s in zip(rows, sigs):
+            r[: len(s)] = s
+    energies = [np.sum(s ** 2) for s in sigs]
     ref_idx = int(np.argmax(energies))
+    nref = lens[ref_idx]
     kpk, win, pkabs, ref_peak = default_engine().xcorr_vs_ref(rows, ref_idx)
-    n = rows.shape[1]
     limit = int(fs * 0.05)
     shifts: List[float] = []
     for idx in range(rows.shape[0]):
         if idx == ref_idx:
             shifts.append(0)
             continue
-        pk = int(kpk[idx])
+        pk = int(kpk[idx]) - (lmax - nref)              # index into the reference's own len(sig) + len(ref) - 1 sequence
         refined = pk
         if pkabs[idx] < 0.3 * ref_peak:
             log.warning("low correlation peak for signal %d during synchronisation", idx)   # shift is NOT zeroed (SURVEY Q7)
-        elif use_interpolation and 1 < pk < 2 * n - 3:
+        elif use_interpolation and 1 < pk < lens[idx] + nref - 3:
             fine = np.linspace(pk - 2, pk + 2, 100)
             refined = fine[np.argmax(np.abs(CubicSpline(np.arange(pk - 2, pk + 3), win[idx])(fine)))]
-        shift = refined - (n - 1)
+        shift = refined - (nref - 1)
         if abs(shift) > limit:
             log.warning("shift of %s samples for signal %d is implausible, using 0", shift, idx)
             shift = 0
         shifts.append(shift)
     lowest = min(shifts)
-    padded = [np.pad(np.asarray(s, dtype=np.float64), (max(0, int(round(sh - lowest))), 0)) for s, sh in zip(signals, shifts)]
+    padded = [np.pad(s, (max(0, int(round(sh - lowest))), 0)) for s, sh in zip(sigs, shifts)]
     length = max(len(p) for p in padded)
     return [np.pad(p, (0, length - len(p))) for p in padded]
 

@@ -185,3 +185,10 @@ def c5_case(frame):
     return _pack(cases.c5_base(frame),
                  geometry(cases.c5_source(frame), cases.grid_array_64(), 48000, 0.25, 1000, cases.DEFAULT_PLANES,
                           cases.LOW_LOSS), 48000)
+
+
+def loc_case():
+    cfg = cases.loc_config(False)
+    return _pack(O.generate_signal("chirp", cfg["fs"], cfg["duration"], cfg["freq"]),
+                 geometry(cfg["source_position"], np.array(cfg["mic_positions"]), cfg["fs"], cfg["duration"], cfg["freq"], [],
+                          O.MATERIALS_DEFAULT), cfg["fs"])

@@ -48,3 +48,24 @@ def test_position_c3_grid64(golden):
     mics = cases.grid_array_64()
     pos = solve_position(mics, [tuple(p) for p in pair_list(64)], _tdoas(g, "", 48000), cases.C_SOUND)
     assert np.max(np.abs(pos - g["position"])) <= 1e-3
+
+
+def test_positions_with_calibration_correction_and_snr_weights(golden):
+    """main.py:209-212 (td - (delay_j - delay_i)) and main.py:254-257 (SNR weights from the per-pair metrics): the
+    reference's own selected indices and SNRs in, the reference's positions out."""
+    from pyaudiolocalization_amd.utils import compute_weights
+    g = golden("localize_extras.npz")
+    cfg = cases.loc_config(False)
+    mics = np.array(cfg["mic_positions"])
+    pairs = [tuple(p) for p in pair_list(5)]
+    td = np.array(_tdoas(g, "loc_", cfg["fs"]))
+    assert np.max(np.abs(solve_position(mics, pairs, list(td), cases.C_SOUND) - g["loc_position_plain"])) <= 1e-3
+    assert np.max(np.abs(g["loc_position_badcalib"] - g["loc_position_plain"])) == 0      # main.py:148-150: ignored
+    delays = np.array([d["delay"] for d in cases.LOC_CALIBRATION])
+    tdc = [t - (delays[j] - delays[i]) for t, (i, j) in zip(td, pairs)]
+    assert np.max(np.abs(solve_position(mics, pairs, tdc, cases.C_SOUND) - g["loc_position_calib"])) <= 1e-3
+    assert [tuple(p) for p in g["loc_metric_pairs"]] == pairs
+    metrics = {p: {"snr": s} for p, s in zip(pairs, g["loc_snr"])}
+    w = compute_weights(metrics, pairs)
+    assert np.max(np.abs(solve_position(mics, pairs, tdc, cases.C_SOUND, w) - g["loc_position_metrics"])) <= 1e-3
+    assert np.max(np.abs(g["loc_position_metrics"] - g["loc_position_calib"])) > 0        # the weights do matter here

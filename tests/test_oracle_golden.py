@@ -130,6 +130,19 @@ def test_metric_frames_first8(golden):
         check_table(IMPL.pair_table(frames, 44100, med, idx), g, tag_of(med), idx, exact_values=True)
 
 
+def test_localize_extras_chain_and_unequal_sync(golden):
+    """Fixture of main.py:147-157,209-222 (calibration correction, per-pair metrics): the oracle's stage chain is the
+    reference's bit for bit on that case, and synchronize_signals_improved on unequal-length signals (utils.py:407-457)."""
+    g = golden("localize_extras.npz")
+    stages.run_chain(IMPL, g, "loc_", *stages.loc_case(), (0.05,))
+    sigs, fs = cases.unequal_sync_signals()
+    assert len({len(s) for s in sigs}) > 1
+    synced = O.synchronize_signals(sigs, fs)
+    assert np.array_equal([len(s) for s in synced], g["uneq_len"])
+    assert np.array_equal([int(np.flatnonzero(s)[0]) for s in synced], g["uneq_first_nonzero"])
+    digest_close(synced, g["uneq_digest"], 1e-13)
+
+
 def test_calibration_path(golden):
     """calibration.py: oracle restatement against run_calibration of the unmodified reference, with the
     reference's own noise draws (np.random.seed in front of the call, one normal(0, level, N) per microphone)."""
