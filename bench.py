@@ -1,21 +1,22 @@
 #!/usr/bin/env python3
 """Headline benchmark: mic-pair GCC-PHAT correlations per second on 44.1 kHz x 1 s frames.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W                        # the metric workload (BASELINE.json)
+    python bench.py --config {c2,c3,c4,c5} ...                           # the other BASELINE configurations, same path
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path (forward spectra of every mic, all-pairs PHAT whitening +
-exact-length inverse DFT, peak selection with the reference's full fallback chain, SNR/max/min)
-over one batch of synthetic frames that already sits in HBM: 64 mics x 44100 samples per frame,
-2016 pairs per frame, float64 (the reference's precision; selected indices are bit-identical).
-Frames are independent, so N ranks (one process per GPU) each own their frames - weak scaling, no
-data-path collective - and every step ends with ONE all-gather of the 48-byte-per-pair TDOA tables
-(RCCL over xGMI through the engine's own communicator; torch.distributed/gloo only carries the
-barrier, the unique id and the max-over-ranks of the elapsed time).
+One step = one pass of the hot path (forward spectra of every microphone, all-pairs PHAT whitening + exact-length
+inverse DFT, peak selection with the reference's full fallback chain, SNR / max / min) over one batch of synthetic
+frames that already sits in HBM; float64 like the reference (selected indices are bit-identical).  Frames are
+independent, so N ranks (one process per GPU) each own their frames - weak scaling, no data-path collective - and
+every step ends with ONE all-gather of the 48-byte-per-pair TDOA tables (RCCL over xGMI through the engine's own
+communicator; torch.distributed / gloo only carries the barrier, the unique id and the max-over-ranks of the time).
 
-Rank 0 prints one JSON line.  ``roofline`` prices the dominant kernel, measured live with HIP
-events on the engine's stream inside the timed region; ``cpu_baseline`` times the NumPy oracle
-(same pocketfft calls as the reference) on one host core over a bounded sample of the same frame.
+Rank 0 prints one JSON line.  `roofline` is the HBM roofline BASELINE.json asks for: `frac` is the WHOLE JOB
+(pairs/s x algorithmic bytes per pair / 8 TB/s); the dominant kernel is priced beside it with its own compulsory
+bytes and its duration from a single-stream calibration pass.  `roofline_fp64` prices the same run against the
+fp64 vector rate, which is what actually binds this path.  `cpu_baseline` times the NumPy
+oracle (the reference's pocketfft calls) on one core and on all cores of the box, BEFORE the GPU is touched.
 """
 from __future__ import annotations
 
@@ -30,8 +31,18 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FS = 44100
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+FP64_PEAK_TFLOPS = 59.0    # v_fma_f64 rate MEASURED on this part (tools/mfma_f64_rate.hip: the clock sits near 1.8 GHz under
+                           # fp64 load; the data-sheet vector figure is 78.6); the guide lists no fp64 vector peak
+
+# BASELINE.json configurations as workloads of THIS path (the pair table); sizes per GPU and step
+CONFIGS = {
+    "metric": dict(fs=44100, mics=64, length=44100, frames=64, label="metric run"),
+    "c2": dict(fs=48000, mics=8, length=48000, frames=256, label="C2 (8-mic array, 48 kHz x 1 s; 256 independent arrays per step)"),
+    "c3": dict(fs=48000, mics=64, length=24000, frames=16, label="C3 (64-mic planar array, 16 trials, 48 kHz x 0.5 s)"),
+    "c4": dict(fs=96000, mics=256, length=96000, frames=1, label="C4 (256-mic sphere, 96 kHz x 1 s, 32 640 pairs)"),
+    "c5": dict(fs=48000, mics=64, length=12000, frames=128, label="C5 (64 mics x 128 of 1024 streaming frames, 48 kHz x 0.25 s)"),
+}
 
 
 def algorithmic_bytes_per_pair(mics: int, length: int, real_bytes: int = 8) -> float:
@@ -42,20 +53,116 @@ def algorithmic_bytes_per_pair(mics: int, length: int, real_bytes: int = 8) -> f
     return 4 * h * real_bytes + (mics / pairs) * (length * real_bytes + 2 * h * real_bytes) + 64
 
 
+def fp64_flops_per_pair(info: dict, mics: int, length: int):
+    """fp64 operations per pair-correlation of the route the plan takes (an FMA counts 2), from the kernels'
+    structure - DESIGN.md section 5 derives every term.  None for routes without a count."""
+    n, n1, n2, tile = info["n"], info.get("n1", 0), info.get("n2", 0), info.get("tile_len", 0)
+    pairs = mics * (mics - 1) // 2
+    stats = 7.0 * n                                             # streaming statistics: min, two shifted sums of squares
+    if n1 and tile == n2 - 1 and n2 == 991:                     # prime-factor cut with Rader rows (9 x 10 x 11)
+        nr = (n1 + 1) // 2
+        whiten = 66.0 * nr * n2                                 # two whitened bins + the packed combinations per position
+        rader = 2 * nr * (2 * (90 * 250 + 110 * 168 + 99 * 92) + 990 * 6)    # two tiles per workgroup: forward + inverse stages, product
+        epilogue = 8.0 * n
+        h = (n1 - 1) // 2
+        cols = n2 * (h * (6 + 8 * h) + 8 * h)                   # dense symmetric N1-point DFT per column, both pairs
+        per_transform = whiten + rader + epilogue + cols        # one packed transform = two pairs
+        forward = per_transform * (mics / 2.0) / pairs          # forward spectra through the same cut, amortised
+        return (per_transform / 2.0) + forward + stats
+    if not n1:                                                  # four-step chirp convolution: 5 M log2 M per FFT, two FFTs + products
+        m = info["conv_len"]
+        fft = 5.0 * m * np.log2(m)
+        per_transform = 2 * fft + 6.0 * m + 66.0 * (n // 2 + 1) + 12.0 * n
+        forward = (2 * 5.0 * info["conv_len"] * np.log2(info["conv_len"])) * mics / pairs
+        return per_transform / 2.0 + forward + stats
+    return None
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, len(os.sched_getaffinity(0))
+
+
+_SHARED = {}          # frame 0 for the forked pool workers (copy-on-write: nothing is pickled per task)
+
+
+def _cpu_pairs(args):
+    """Worker of the all-cores leg: the oracle's get_time_delays_phat-equivalent for a block of pairs of one frame."""
+    pairs, fs, med = args
+    rows = _SHARED["frame0"]
+    from oracle import pal_oracle as O
+    out = []
+    for i, j in pairs:
+        rec = O.pair_record(O.phat_correlation(rows[i], rows[j]), rows.shape[1], fs, max_expected_delay=med)
+        out.append((rec["k_sel"], rec["branch"], rec["cmax"]))
+    return out
+
+
+def cpu_baseline(frame0: np.ndarray, fs: float, med, cpu_mics: int, budget_s: float = 12.0):
+    """Reference CPU path (NumPy oracle = the reference's pocketfft calls) on this box's host cores: one core (the
+    reference is single-threaded), then a process pool over pairs on every core.  Runs before any HIP call."""
+    import multiprocessing as mp
+    from oracle import pal_oracle as O
+    m = frame0.shape[0]
+    cm = min(cpu_mics, m)
+    t1 = time.perf_counter()
+    want = O.all_pairs(frame0[:cm], fs, max_expected_delay=med)
+    one_s = time.perf_counter() - t1
+    cpairs = cm * (cm - 1) // 2
+    model, cores = cpu_info()
+    rate1 = cpairs / one_s
+    # all cores: as many pairs of the same frame as fit the time budget at the single-core rate
+    full = [(i, j) for i in range(m) for j in range(i + 1, m)]
+    take = int(min(len(full), max(cores * 4, rate1 * cores * budget_s * 0.8)))
+    blocks = [full[k::cores * 4] for k in range(cores * 4)]
+    blocks = [b[: max(1, take // (cores * 4))] for b in blocks if b]
+    npool = sum(len(b) for b in blocks)
+    all_rate, all_s = None, None
+    try:
+        _SHARED["frame0"] = frame0
+        ctx = mp.get_context("fork")                              # (no GPU state exists yet in this process)
+        with ctx.Pool(cores) as pool:
+            pool.map(_cpu_pairs, [(b[:1], fs, med) for b in blocks[:cores]])      # imports + FFT plans
+            t2 = time.perf_counter()
+            pool.map(_cpu_pairs, [(b, fs, med) for b in blocks])
+            all_s = time.perf_counter() - t2
+        all_rate = npool / all_s
+    except Exception as exc:                                      # reported, never silent
+        print(f"[bench] all-cores CPU leg failed: {exc}", file=sys.stderr)
+    cpu = {"value": round(rate1, 2), "unit": "pair-correlations/s", "cores": 1, "kind": "port",
+           "sample": f"all {cpairs} pairs of the first {cm} mics of frame 0 ({one_s:.1f} s, NumPy/pocketfft oracle, "
+                     "3 exact-length FFTs per pair like utils.py:114-118)",
+           "all_cores": {"value": round(all_rate, 2) if all_rate else None, "cores": cores,
+                         "sample": f"{npool} pairs of frame 0 over a pool of {cores} processes ({all_s:.1f} s)" if all_s else "failed"},
+           "cpu_model": model, "host_cores": cores}
+    return cpu, want, cm
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=16, help="frames per step per GPU (one batch = one step)")
-    ap.add_argument("--mics", type=int, default=64)
-    ap.add_argument("--length", type=int, default=44100)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="metric",
+                    help="metric = BASELINE.json's headline workload; c2..c5 = the other configurations on the same path")
+    ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (0 = the configuration's default)")
+    ap.add_argument("--mics", type=int, default=0)
+    ap.add_argument("--length", type=int, default=0)
+    ap.add_argument("--fs", type=float, default=0)
     ap.add_argument("--max-expected-delay", type=float, default=0.05, help="seconds; negative = None")
     ap.add_argument("--chunk", type=int, default=0, help="transforms per launch group (0 = engine default)")
-    ap.add_argument("--cpu-mics", type=int, default=24, help="mics of frame 0 in the CPU baseline / parity sample")
+    ap.add_argument("--cpu-mics", type=int, default=24, help="mics of frame 0 in the single-core CPU baseline / parity sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
-    ap.add_argument("--event-every", type=int, default=5, help="HIP events around every n-th launch group (1 = all; 5 rotates through the 8 groups of a 64-mic frame)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: no HIP events around the kernels (roofline kernel block = null)")
+    ap.add_argument("--event-every", type=int, default=5, help="HIP events around every n-th launch group (1 = all)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,9 +170,21 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    cfg = CONFIGS[args.config]
+    fs = float(args.fs or cfg["fs"])
+    b, m, length = args.frames or cfg["frames"], args.mics or cfg["mics"], args.length or cfg["length"]
+    pairs = m * (m - 1) // 2
+    med = None if args.max_expected_delay < 0 else args.max_expected_delay
+
+    from pyaudiolocalization_amd.synthetic import metric_frames
+    frames = metric_frames(b, m, length, first=rank * b)          # this rank's own frames (weak scaling)
+
+    # ---- CPU baseline first: host cores only, before this process initialises the GPU -------------------------------
+    cpu, want, cm = None, None, 0
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, want, cm = cpu_baseline(frames[0], fs, med, args.cpu_mics if args.config == "metric" else min(args.cpu_mics, 12))
 
     from pyaudiolocalization_amd import Engine, RECORD, make_params, pair_list
-    from pyaudiolocalization_amd.synthetic import metric_frames
 
     dist = None
     if world > 1:
@@ -75,15 +194,12 @@ def main() -> None:
         dist = dist_mod
 
     # one process per GPU; PAL_BENCH_SHARE_GPU=1 lets a rehearsal on a one-GPU box put every rank on device 0
-    eng = Engine(0 if os.environ.get("PAL_BENCH_SHARE_GPU") == "1" else local_rank)
+    share = os.environ.get("PAL_BENCH_SHARE_GPU") == "1"
+    eng = Engine(0 if share else local_rank)
     if args.chunk > 0:
         eng.set_chunk(args.chunk)
-    b, m, length = args.frames, args.mics, args.length
-    pairs = m * (m - 1) // 2
-    med = None if args.max_expected_delay < 0 else args.max_expected_delay
-    prm = make_params(FS, 1, "median", 1.0, med)
+    prm = make_params(fs, 1, "median", 1.0, med)
 
-    frames = metric_frames(b, m, length, first=rank * b)          # this rank's own frames (weak scaling)
     d_frames = eng.alloc(frames.nbytes)
     eng.upload(d_frames, frames)
     tbytes = b * pairs * RECORD.itemsize
@@ -92,18 +208,22 @@ def main() -> None:
 
     gather = "none"
     if world > 1:
-        import torch
-        try:                                                      # engine-native RCCL communicator
-            ident = [Engine.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ident, src=0)
-            eng.comm_init(world, rank, ident[0])
-            gather = "rccl-allgather"
-        except Exception as exc:                                  # reported, never silent
-            print(f"[rank {rank}] RCCL init failed ({exc}); gathering through gloo host tensors", file=sys.stderr)
-            gather = "gloo-host"
+        if share:
+            # RCCL refuses two ranks on one device (ncclCommInitRank: "unhandled cuda error" - duplicate GPU); a one-GPU
+            # rehearsal therefore gathers through gloo and says so
+            gather = "gloo-host (ranks share one GPU: RCCL needs one device per rank)"
+        else:
+            try:                                                      # engine-native RCCL communicator
+                ident = [Engine.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ident, src=0)
+                eng.comm_init(world, rank, ident[0])
+                gather = "rccl-allgather"
+            except Exception as exc:                                  # reported, never silent
+                print(f"[rank {rank}] RCCL init failed ({exc}); gathering through gloo host tensors", file=sys.stderr)
+                gather = "gloo-host"
         flags = [None] * world
         dist.all_gather_object(flags, gather)
-        if any(f != "rccl-allgather" for f in flags):
+        if any(f != "rccl-allgather" for f in flags) and gather == "rccl-allgather":
             gather = "gloo-host"
 
     host_table = np.zeros((b, pairs), dtype=RECORD)
@@ -112,7 +232,7 @@ def main() -> None:
         eng.gcc_phat_all_pairs_dev(d_frames, b, m, length, prm, d_table)
         if gather == "rccl-allgather":
             eng.all_gather_dev(d_table, d_all, tbytes)
-        elif gather == "gloo-host":
+        elif gather.startswith("gloo-host"):
             from pyaudiolocalization_amd.distributed import gather_tables_torch
             eng.synchronize()
             eng.download(host_table, d_table)
@@ -146,31 +266,32 @@ def main() -> None:
     total_pairs = args.steps * b * pairs * world
     value = total_pairs / elapsed
 
-    # ---- dominant kernel, HIP events on the engine's stream --------------------------------------
+    # ---- per-kernel durations: live (HIP events inside the timed region, three streams share the CUs) and alone
+    #      (one untimed calibration frame on a second, single-stream engine: PAL_OVERLAP=0, events around every launch)
     entries = eng.profile_entries()
     kernels = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in entries.items() if v[1] > 0}
-    # Which kernel is "dominant": in the two-stream run a latency-bound launch (one workgroup per row) waits for slots
-    # beside the other stream's FFT passes and its elapsed time stretches severalfold, so elapsed totals do not rank the
-    # kernels by work.  One untimed calibration frame on a second, single-stream engine (PAL_OVERLAP=0, events around
-    # every launch) ranks them by their time alone; the roofline then uses THAT kernel's live duration from the timed run.
     alone, alone_avg = {}, {}
+    cal_pairs_per_launch = 0.0
     if rank == 0 and entries:
         saved = os.environ.get("PAL_OVERLAP")
         os.environ["PAL_OVERLAP"] = "0"
         cal = None
         try:
-            cal = Engine(0 if os.environ.get("PAL_BENCH_SHARE_GPU") == "1" else local_rank)
-            one = frames[:1]
-            d_one, d_tab = cal.alloc(one.nbytes), cal.alloc(pairs * RECORD.itemsize)
+            cal = Engine(0 if share else local_rank)
+            cb = min(b, max(1, -(-2 * eng.pair_group_size(length) // pairs)))       # frames that fill one launch group
+            one = frames[:cb]
+            d_one, d_tab = cal.alloc(one.nbytes), cal.alloc(cb * pairs * RECORD.itemsize)
             cal.upload(d_one, one)
-            cal.gcc_phat_all_pairs_dev(d_one, 1, m, length, prm, d_tab)      # plans, tables, scratch
+            cal.gcc_phat_all_pairs_dev(d_one, cb, m, length, prm, d_tab)      # plans, tables, scratch
             cal.synchronize()
             cal.profile_begin(every=1)
-            cal.gcc_phat_all_pairs_dev(d_one, 1, m, length, prm, d_tab)
+            cal.gcc_phat_all_pairs_dev(d_one, cb, m, length, prm, d_tab)
             cal.synchronize()
             cal.profile_end()
             alone = {k: v[0] for k, v in cal.profile_entries().items() if v[1] > 0}
             alone_avg = {k: v[0] / v[1] for k, v in cal.profile_entries().items() if v[1] > 0}
+            cal_groups = -(-((cb * pairs + 1) // 2) // eng.pair_group_size(length))
+            cal_pairs_per_launch = cb * pairs / cal_groups
         except Exception as exc:                                  # reported, never silent: the ranking falls back to elapsed totals
             print(f"[bench] calibration frame failed ({exc}); ranking kernels by elapsed time", file=sys.stderr)
             alone, alone_avg = {}, {}
@@ -185,77 +306,100 @@ def main() -> None:
     dom = (ranked[0], entries[ranked[0]]) if ranked else (max(entries.items(), key=lambda kv: kv[1][0]) if entries else ("none", (0.0, 0)))
     dom_name, (dom_ms, dom_launches) = dom
     b_alg = algorithmic_bytes_per_pair(m, length)
-    # pairs one launch of the pair pipeline processes: a step is cut into launch groups of `chunk` packed transforms
-    # (two pairs each); the events sample every args.event_every-th group, so the launch COUNT says nothing here
     chunk = eng.pair_group_size(length)
     groups_per_step = -(-((b * pairs + 1) // 2) // chunk)
     pairs_per_launch = b * pairs / groups_per_step
-    roofline = None
+    info = eng.plan_info(length)
+    h_bins = length
+    # compulsory bytes of ONE pair inside each kernel class of the prime-factor / four-step pipelines (what that kernel
+    # must move for a pair even with perfect caching): spectra in, workspace out / in, correlation row out / in
+    n = info["n"]
+    spec_b, corr_b = 4 * h_bins * 8, n * 8                        # two half spectra in, one correlation row
+    y_b = n * 16 / 2                                              # prime-factor grid Y: one complex transform per two pairs
+    w_b = info["conv_len"] * 16 / 2                               # four-step workspace W per pair
+
+    def own(name):
+        if "k_pfa_cols" in name: return y_b + corr_b              # (also the fused k_pfa_cols_stats)
+        if "k_pfa_rows" in name: return spec_b + y_b
+        if "k_peak_stream" in name: return corr_b
+        if name.startswith("k_cols") and "_fwd" in name: return spec_b + w_b
+        if name.startswith("k_rows"): return 2 * w_b
+        if name.startswith("k_cols") and "_inv" in name: return w_b + corr_b
+        return None
+
+    achieved_job = value / world * b_alg / 1e9                     # per GPU
+    roofline = {"bound": "hbm", "achieved": round(achieved_job, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved_job / HBM_PEAK_GBS, 5),
+                "frac_is": "whole job per GPU: pairs/s x algorithmic bytes per pair / peak",
+                "algorithmic_bytes_per_pair": round(b_alg, 1), "traffic": None, "kernel": None}
     if dom_launches:
-        avg_s = dom_ms * 1e-3 / dom_launches
-        achieved = b_alg * pairs_per_launch / avg_s / 1e9
-        traffic = None
+        live_s = dom_ms * 1e-3 / dom_launches
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(dom_name)
+                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command, NOT this run)"
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": dom_name,
-                    "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": dom_launches,
-                    "event_sampling": f"every {args.event_every}th launch group",
-                    "dominant_by": "largest time alone (one serial calibration frame)" if ranked else "largest elapsed time",
-                    # the same launch alone on the GPU (calibration frame, launch groups of 256 transforms): what the kernel
-                    # itself reaches; `frac` above is measured while two other launch groups share the CUs
-                    "alone_launch_us": round(alone_avg[dom_name] * 1e3, 2) if dom_name in alone_avg else None,
-                    "frac_alone": (round(b_alg * min(pairs_per_launch, pairs / max(1, -(-((pairs + 1) // 2) // chunk)))
-                                         / (alone_avg[dom_name] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                                   if dom_name in alone_avg else None),
-                    "algorithmic_bytes_per_pair": round(b_alg, 1),
-                    "pairs_per_launch": round(pairs_per_launch, 2)}
+        kb = own(dom_name)
+        roofline.update({
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": dom_name,
+            "dominant_by": "largest time alone (single-stream calibration pass)" if ranked else "largest elapsed time",
+            "kernel_alone_launch_us": round(alone_avg[dom_name] * 1e3, 2) if dom_name in alone_avg else None,
+            "kernel_live_launch_us": round(live_s * 1e6, 2),
+            "kernel_live_note": "HIP events inside the timed region; three launch groups share the CUs, so this duration is stretched by concurrency",
+            "kernel_own_bytes_per_pair": kb,
+            "kernel_frac_alone": (round(kb * cal_pairs_per_launch / (alone_avg[dom_name] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                  if kb and dom_name in alone_avg else None),
+            "launches_timed": dom_launches, "event_sampling": f"every {args.event_every}th launch group",
+            "pairs_per_launch": round(pairs_per_launch, 2)})
+    flops = fp64_flops_per_pair(info, m, length)
+    roofline_fp64 = None
+    if flops:
+        tf = value / world * flops / 1e12
+        roofline_fp64 = {"bound": "fp64-valu", "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / FP64_PEAK_TFLOPS, 4), "flops_per_pair": round(flops),
+                         "peak_source": "v_fma_f64 rate measured on MI355X (tools/mfma_f64_rate.hip); data sheet 78.6",
+                         "flops_source": "operation count of the kernels' structure (DESIGN.md section 5), FMA = 2"}
+    binding = None
+    if roofline_fp64:
+        binding = "fp64-valu" if roofline_fp64["frac"] > roofline["frac"] else "hbm"
 
-    # ---- CPU baseline + parity sample (rank 0, N = 1 only) ---------------------------------------------
-    cpu = None
+    # ---- parity sample against the CPU oracle's rows computed above ------------------------------------------------
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import pal_oracle as O                       # checker + baseline only, never the product path
-        cm = min(args.cpu_mics, m)
-        t1 = time.perf_counter()
-        want = O.all_pairs(frames[0, :cm], FS, max_expected_delay=med)
-        cpu_s = time.perf_counter() - t1
-        cpairs = cm * (cm - 1) // 2
-        cpu = {"value": round(cpairs / cpu_s, 2), "unit": "pair-correlations/s", "cores": 1, "kind": "port",
-               "sample": f"all {cpairs} pairs of the first {cm} mics of frame 0 ({cpu_s:.1f} s, NumPy/pocketfft oracle, "
-                         "3 exact-length FFTs per pair like utils.py:114-118)"}
+    if want is not None:
         full = pair_list(m)
         pick = np.flatnonzero((full[:, 0] < cm) & (full[:, 1] < cm))
         got = host_table[0][pick]
-        parity = {"pairs_checked": int(cpairs), "k_sel_equal": int(np.count_nonzero(got["k_sel"] == want["k_sel"])),
+        parity = {"pairs_checked": int(pick.size), "k_sel_equal": int(np.count_nonzero(got["k_sel"] == want["k_sel"])),
                   "branch_equal": int(np.count_nonzero(got["branch"] == want["branch"])),
                   "max_rel_err_cmax": float(np.max(np.abs(got["cmax"] - want["cmax"]) / np.abs(want["cmax"])))}
 
     if rank == 0:
-        info = eng.plan_info(length)
+        if info.get("n1"):
+            rader = info["tile_len"] == info["n2"] - 1
+            route = (f"n={info['n']} = {info['n1']} x {info['n2']}: prime-factor inverse, "
+                     + (f"Rader row DFTs (cyclic convolutions of {info['n2'] - 1} points in LDS)" if rader
+                        else f"in-LDS chirp convolutions of {info['tile_len']} points")
+                     + " + dense column DFTs")
+        else:
+            route = f"n={info['n']}: four-step chirp convolution {info['m1']}x{info['m2']}"
         line = {
-            "metric": "mic-pair GCC-PHAT correlations/s @44.1kHz·1s",
+            "metric": "mic-pair GCC-PHAT correlations/s @44.1kHz·1s" if args.config == "metric" and length == 44100
+                      else f"mic-pair GCC-PHAT correlations/s @{fs / 1000:g}kHz·{length / fs:g}s",
             "value": round(value, 1), "unit": "pair-correlations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"metric run: {b} frame(s)/step/GPU x {m} mics x {length} samples @ {FS} Hz, "
-                                   f"{pairs} pairs/frame, max_expected_delay={med}, exact DFT length n={info['n']}"
-                                   + (f" = {info['n1']} x {info['n2']} (prime-factor inverse: "
-                                      + (f"Rader row DFTs, cyclic convolutions of {info['n2'] - 1} points in LDS"
-                                         if info['tile_len'] & (info['tile_len'] - 1) else
-                                         f"in-LDS chirp convolutions of {info['tile_len']} points")
-                                      + " + dense column DFTs; forward spectra "
-                                      + ("through the same cut, two real frames per transform)"
-                                         if info['tile_len'] & (info['tile_len'] - 1) and os.environ.get("PAL_PFA_FWD", "1") != "0" else
-                                         f"via chirp convolution {info['m1']}x{info['m2']})") if info.get("n1") else
-                                      f" via chirp convolution {info['m1']}x{info['m2']}"),
-                       "frames_per_step_per_gpu": b, "mics": m, "samples": length, "pairs_per_frame": pairs,
+            "config": {"workload": f"{cfg['label']}: {b} frame(s)/step/GPU x {m} mics x {length} samples @ {fs:g} Hz, "
+                                   f"{pairs} pairs/frame, max_expected_delay={med}; {route}",
+                       "name": args.config, "frames_per_step_per_gpu": b, "mics": m, "samples": length, "pairs_per_frame": pairs,
+                       "fused_column_statistics": os.environ.get("PAL_FUSED", "default"),
                        "gather": gather, "parallelism": f"frames sharded over {world} GPU(s)"},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels_ms": kernels,
+            "roofline": roofline, "roofline_fp64": roofline_fp64, "binding_roofline": binding,
+            "cpu_baseline": cpu, "parity": parity, "kernels_ms": kernels,
+            "kernels_alone_us": {k: round(v * 1e3, 2) for k, v in alone_avg.items()},
+            "timed_region_s": round(elapsed, 3),
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

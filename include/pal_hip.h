@@ -79,6 +79,10 @@ int pal_synchronize(pal_handle h);
 /* transforms processed per launch group (workspace = chunk * M * 16 B); 0 keeps the default: 128, and for the pair
  * pipeline (two pairs per transform) 240 where one workspace slot stays below 1 GiB, 32 at least */
 int pal_set_chunk(pal_handle h, int chunk);
+/* Plans (chirps, chirp spectra, prime-factor tables: a few MB per transform length) are built on first use and cached
+ * per length, at most 32 of them (PAL_MAX_PLANS), least recently used out first; pal_clear_plans drops them all now
+ * (after draining the engine's streams).  The reference keeps no such state (numpy.fft plans are per call). */
+int pal_clear_plans(pal_handle h);
 /* packed transforms (pairs / 2) one launch group of the all-pairs pipeline carries for frames of L samples */
 int pal_pair_group_size(pal_handle h, int L, int32_t* transforms);
 
@@ -98,12 +102,23 @@ int pal_gcc_phat_all_pairs(pal_handle h, const double* frames, int B, int M, int
                            pal_pair_record* table, double* corr);
 int pal_gcc_phat_all_pairs_dev(pal_handle h, const double* d_frames, int B, int M, int L, const pal_phat_params* prm,
                                pal_pair_record* d_table);
+/* Non-finite samples: the reference confines a NaN to the pairs of its own microphone.  Here two pairs share one complex
+ * transform, so a frame with a NaN or an infinity makes the batched calls (all_pairs, pairs) fail with PAL_ERR_INVALID
+ * (reported by the call itself, or by pal_synchronize for the _dev forms) instead of returning rows that differ from the
+ * reference's.  The single-pair entry points below have no partner pair and behave like the reference. */
 
 /* explicit pair list over rows[R][L]: pairs[P][2] row indices -> table[P].  Carries the 1000 shuffled
  * correlations per pair of bootstrap_significance (utils.py:183-216) as one call (rows = sig1 + shuffles of sig2,
  * pairs = (0, k)); only cmax of each record is used there. */
 int pal_gcc_phat_pairs(pal_handle h, const double* rows, int R, int L, const int32_t* pairs, int64_t P,
                        const pal_phat_params* prm, pal_pair_record* table);
+
+/* the same with the rows, the pair list (int32 [P][2]) and the table in HBM; asynchronous like every _dev entry point.
+ * This is what a rank calls for its contiguous block of the ordered pair list when ONE large frame (256 microphones,
+ * 32 640 pairs) is split over the GPUs of a node: every rank holds the frame and recomputes the spectra locally.
+ * A row index outside 0..R-1 is reported as PAL_ERR_INVALID by pal_synchronize. */
+int pal_gcc_phat_pairs_dev(pal_handle h, const double* d_rows, int R, int L, const int32_t* d_pairs, int64_t P,
+                           const pal_phat_params* prm, pal_pair_record* d_table);
 
 /* single-pair signatures: phat_correlation(sig1, sig2) (utils.py:108) -> corr[n1+n2-1] */
 int pal_phat_correlation(pal_handle h, const double* sig1, int n1, const double* sig2, int n2, double* corr);
@@ -144,6 +159,26 @@ int pal_wiener3(pal_handle h, const double* rows, int R, int N, double* out);
  * pkabs = |corr[kpk]|, *refpk = max|autocorrelation of the reference|. */
 int pal_xcorr_vs_ref(pal_handle h, const double* rows, int R, int N, int ref_idx, int32_t* kpk, double* win5,
                      double* pkabs, double* refpk);
+
+/* ---- device-resident stage chain (main.py:165-204 without host copies of the waveforms) ----------------------------
+ * The streaming configuration (64 microphones x 1024 frames, multipath simulation on) keeps every waveform in HBM:
+ * simulate -> measure the synchronisation shifts -> align -> prefilter -> all pairs.  The host supplies the path tables
+ * and the filter coefficients and reads back five numbers per row (the 5-point spline refinement and the integer pads of
+ * utils.py:428-451 stay host work, as in pal_xcorr_vs_ref).  All `d_` pointers come from pal_device_alloc.
+ *
+ * pal_simulate_multipath_dev: as pal_simulate_multipath with d_base[B][nbase], d_delays / d_gains[B][M][K], d_out[B][M][out_len].
+ * pal_sync_measure_dev: per frame b of d_rows[B][M][N]: ref_idx[b] = argmax of the row energies (utils.py:413-414), then
+ *   pal_xcorr_vs_ref of the frame's rows against that row: kpk[B][M], win5[B][M][5], pkabs[B][M], refpk[B] (host arrays).
+ * pal_align_rows_dev: utils.py:448-456 - d_out[r][pad_left[r] + i] = d_rows[r][i], zeros elsewhere (rows of Lout samples).
+ * pal_filtfilt_dev / pal_wiener3_dev: as pal_filtfilt / pal_wiener3 on rows in HBM (b, a, zi stay host arrays). */
+int pal_simulate_multipath_dev(pal_handle h, const double* d_base, int B, int nbase, double fs, int total_samples,
+                               const double* d_delays, const double* d_gains, int M, int K, int trim_len, double* d_out);
+int pal_sync_measure_dev(pal_handle h, const double* d_rows, int B, int M, int N, int32_t* ref_idx, int32_t* kpk,
+                         double* win5, double* pkabs, double* refpk);
+int pal_align_rows_dev(pal_handle h, const double* d_rows, int R, int N, const int32_t* pad_left, int Lout, double* d_out);
+int pal_filtfilt_dev(pal_handle h, const double* b, int nb, const double* a, int na, const double* zi, const double* d_rows,
+                     int R, int N, double* d_out);
+int pal_wiener3_dev(pal_handle h, const double* d_rows, int R, int N, double* d_out);
 
 /* ---- multi-GPU: one gather of the TDOA table over RCCL/xGMI ------------------------------ */
 int pal_comm_unique_id(void* id128);                       /* rank 0; 128-byte ncclUniqueId          */

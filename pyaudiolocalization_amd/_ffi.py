@@ -47,6 +47,7 @@ SIGNATURES = {
     "pal_destroy": (None, [_H]),
     "pal_last_error": (C.c_char_p, [_H]),
     "pal_synchronize": (C.c_int, [_H]),
+    "pal_clear_plans": (C.c_int, [_H]),
     "pal_set_chunk": (C.c_int, [_H, C.c_int]),
     "pal_pair_group_size": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int32)]),
     "pal_device_alloc": (C.c_int, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -57,6 +58,7 @@ SIGNATURES = {
                                          C.c_void_p]),
     "pal_gcc_phat_all_pairs_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(PhatParams), C.c_void_p]),
     "pal_gcc_phat_pairs": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(PhatParams), C.c_void_p]),
+    "pal_gcc_phat_pairs_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(PhatParams), C.c_void_p]),
     "pal_phat_correlation": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pal_get_time_delays_phat": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(PhatParams), C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
@@ -73,6 +75,14 @@ SIGNATURES = {
     "pal_wiener3": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pal_xcorr_vs_ref": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_double)]),
+    "pal_simulate_multipath_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pal_sync_measure_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    "pal_align_rows_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "pal_filtfilt_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p]),
+    "pal_wiener3_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pal_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pal_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
     "pal_comm_all_gather": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -177,12 +177,43 @@ struct CorrStorer {
 // Silent channels.  A frame of zeros has a zero spectrum, R = 0 / (0 + 1e-10) = 0 in every bin, and the reference's
 // correlation row is exactly zero (argmax 0, no peaks).  Here two pairs share one complex transform, whose rounding
 // leaves 1e-17 of the OTHER pair in that row: the rows of pairs with a silent microphone are therefore forced to zero.
-__global__ __launch_bounds__(256) void k_row_nonzero(const double* __restrict__ frames, size_t frame_stride, int len, int* __restrict__ flags) {
+// The same pass looks for non-finite samples.  The reference confines a NaN to the pairs of its own microphone; here the
+// pair packed into the same complex transform would be poisoned as well, so a non-finite frame sets bit 2 of the
+// engine's status word and the call is reported as PAL_ERR_INVALID by pal_synchronize (never silently wrong rows).
+__global__ __launch_bounds__(256) void k_row_nonzero(const double* __restrict__ frames, size_t frame_stride, int len, int* __restrict__ flags,
+                                                     int* __restrict__ status) {
   const double* x = frames + size_t(blockIdx.x) * frame_stride;
-  bool any = false;
-  for (int i = threadIdx.x; i < len; i += 256) any = any || x[i] != 0.0;
+  bool any = false, bad = false;
+  for (int i = threadIdx.x; i < len; i += 256) {
+    const double v = x[i];
+    any = any || v != 0.0;
+    bad = bad || !(v - v == 0.0);                             // NaN or infinity
+  }
   const int all = __syncthreads_or(any ? 1 : 0);
-  if (threadIdx.x == 0) flags[blockIdx.x] = all;
+  const int nonfinite = __syncthreads_or(bad ? 1 : 0);
+  if (threadIdx.x == 0) {
+    flags[blockIdx.x] = all;
+    if (nonfinite && status) atomicOr(status + 2, 1);
+  }
+}
+
+// explicit pair list (row indices, two per pair) -> the packed table of the pair pipeline: two pairs per complex
+// transform, (c, d) = (-1, -1) when the count is odd.  A row index outside 0..R-1 sets bit 1 of status word 2 and the
+// pair is redirected to row 0 (no out-of-range read; pal_synchronize reports PAL_ERR_INVALID).
+__global__ __launch_bounds__(256) void k_pairs_to_quads(const int32_t* __restrict__ pairs, int64_t P, int R, int4* __restrict__ quads,
+                                                        int* __restrict__ status) {
+  const int64_t g = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (g >= (P + 1) / 2) return;
+  int v[4];
+  bool bad = false;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t at = 4 * g + q;
+    v[q] = at < 2 * P ? pairs[at] : -1;
+    if (at < 2 * P && (v[q] < 0 || v[q] >= R)) { bad = true; v[q] = 0; }
+  }
+  quads[g] = make_int4(v[0], v[1], v[2], v[3]);
+  if (bad && status) atomicOr(status + 2, 2);
 }
 
 __global__ __launch_bounds__(256) void k_pair_zero(const int4* __restrict__ quads, const int* __restrict__ nonzero, int64_t ntr,
@@ -266,29 +297,96 @@ int Engine::build_conv(Conv& c, const cd* w, int n, int neg_count, int pos_count
   return PAL_OK;
 }
 
+void Engine::free_plan(Plan& pl) {
+  if (pl.w) (void)hipFree(pl.w);
+  free_conv(pl.fwd);
+  free_conv(pl.inv);
+  free_pfa(pl.pfa);
+  pl = Plan();
+}
+
+// every plan and the cached synchronisation convolutions; the streams are drained first
+int Engine::clear_plans() {
+  PAL_HIP(hipStreamSynchronize(stream));
+  PAL_HIP(hipStreamSynchronize(stream2));
+  PAL_HIP(hipStreamSynchronize(stream3));
+  for (auto& kv : plans) free_plan(kv.second);
+  plans.clear();
+  for (auto& kv : xconvs) free_conv(kv.second.conv);
+  xconvs.clear();
+  return PAL_OK;
+}
+
+// convolution geometry of the plain cross-correlation of pal_xcorr_vs_ref for sequences of `len` points, kept per
+// length (at most max_plans of them, least recently used out first)
+int Engine::xcorr_conv(size_t len, Conv** out) {
+  auto it = xconvs.find(len);
+  if (it == xconvs.end()) {
+    if (int(xconvs.size()) >= max_plans) {
+      auto old = xconvs.begin();
+      for (auto k = xconvs.begin(); k != xconvs.end(); ++k)
+        if (k->second.used < old->second.used) old = k;
+      PAL_HIP(hipStreamSynchronize(stream));
+      free_conv(old->second.conv);
+      xconvs.erase(old);
+    }
+    XConv x;
+    const int rc = alloc_conv(x.conv, len);
+    if (rc != PAL_OK) { free_conv(x.conv); return rc; }
+    it = xconvs.emplace(len, x).first;
+  }
+  it->second.used = ++plan_clock;
+  *out = &it->second.conv;
+  return PAL_OK;
+}
+
 int Engine::get_plan(int n, int lin, int nout, Plan** out) {
   auto key = std::make_tuple(n, lin, nout);
   auto it = plans.find(key);
   if (it != plans.end()) {
+    it->second.used = ++plan_clock;
     *out = &it->second;
     return PAL_OK;
   }
   if (n < 1 || lin < 1 || lin > n || nout < 1 || nout > n)
     return fail(PAL_ERR_INVALID, "bad transform geometry n=%d lin=%d nout=%d", n, lin, nout);
+  // The cache is bounded (recordings of many different lengths, ragged pairs, per-frame lengths behind the
+  // synchronisation): the least recently used plan goes once every stream has drained (PAL_MAX_PLANS, default 32).
+  while (int(plans.size()) >= max_plans) {
+    auto old = plans.begin();
+    for (auto k = plans.begin(); k != plans.end(); ++k)
+      if (k->second.used < old->second.used) old = k;
+    PAL_HIP(hipStreamSynchronize(stream));
+    PAL_HIP(hipStreamSynchronize(stream2));
+    PAL_HIP(hipStreamSynchronize(stream3));
+    free_plan(old->second);
+    plans.erase(old);
+  }
   Plan pl;
   pl.n = n;
   pl.H = n / 2 + 1;
   pl.lin = lin;
   pl.nout = nout;
-  PAL_HIP(hipMalloc(&pl.w, size_t(n) * sizeof(cd)));
-  k_make_chirp<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(pl.w, n, 1);
-  PAL_HIP(hipGetLastError());
-  // forward: j < lin inputs, k < H outputs, kernel w_{k-j}
-  PAL_TRY(build_conv(pl.fwd, pl.w, n, lin, pl.H, false, 1.0));
-  // inverse: k < n inputs, m < nout outputs, kernel conj(w_{m-k}); 1/n of numpy.fft.ifft folded in
-  PAL_TRY(build_conv(pl.inv, pl.w, n, n, nout, true, 1.0 / double(n)));
-  PAL_TRY(build_pfa(pl));                      // prime-factor route of the PHAT inverse, when n splits
-  PAL_HIP(hipStreamSynchronize(stream));
+  int rc = PAL_OK;
+  do {
+    if ((rc = check(hipMalloc(&pl.w, size_t(n) * sizeof(cd)), "chirp alloc")) != PAL_OK) break;
+    k_make_chirp<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(pl.w, n, 1);
+    if ((rc = check(hipGetLastError(), "k_make_chirp")) != PAL_OK) break;
+    // forward: j < lin inputs, k < H outputs, kernel w_{k-j}
+    if ((rc = build_conv(pl.fwd, pl.w, n, lin, pl.H, false, 1.0)) != PAL_OK) break;
+    // inverse: k < n inputs, m < nout outputs, kernel conj(w_{m-k}); 1/n of numpy.fft.ifft folded in
+    if ((rc = build_conv(pl.inv, pl.w, n, n, nout, true, 1.0 / double(n))) != PAL_OK) break;
+    if ((rc = build_pfa(pl)) != PAL_OK) break;   // prime-factor route of the PHAT inverse, when n splits
+    rc = check(hipStreamSynchronize(stream), "plan setup");
+  } while (0);
+  if (rc != PAL_OK) {                            // nothing of a half-built plan stays behind
+    const std::string keep = err;
+    (void)hipStreamSynchronize(stream);
+    free_plan(pl);
+    err = keep;
+    return rc;
+  }
+  pl.used = ++plan_clock;
   auto ins = plans.emplace(key, pl);
   *out = &ins.first->second;
   return PAL_OK;
@@ -299,7 +397,9 @@ int Engine::forward_spectra(Plan& pl, const double* frames, size_t frame_stride,
   Engine* e = this;
   if (len > pl.lin) return fail(PAL_ERR_INVALID, "frame length %d exceeds plan input length %d", len, pl.lin);
   if (nonzero && rows > 0) {
-    k_row_nonzero<<<dim3(rows), dim3(256), 0, stream>>>(frames, frame_stride, len, nonzero);
+    void* stp = nullptr;
+    PAL_TRY(scratch(7, 64, &stp));
+    k_row_nonzero<<<dim3(rows), dim3(256), 0, stream>>>(frames, frame_stride, len, nonzero, static_cast<int*>(stp));
     PAL_HIP(hipGetLastError());
   }
   if (pfa_forward_applies(pl, len)) return pfa_forward_spectra(pl, frames, frame_stride, rows, len, spectra);
@@ -323,6 +423,26 @@ int Engine::forward_spectra(Plan& pl, const double* frames, size_t frame_stride,
     }
   }
   return PAL_OK;
+}
+
+// explicit pair list over R equal-length rows, everything in HBM: one-vs-many bootstrap batches, sparse pair sets, and
+// the contiguous pair blocks a rank owns when ONE large frame is split over the GPUs (spectra recomputed locally)
+int Engine::pairs_dev(const double* d_rows, int R, int L, const int32_t* d_pairs, int64_t P, const pal_phat_params& prm,
+                      pal_pair_record* d_table) {
+  if (R < 1 || L < 1 || P < 1) return fail(PAL_ERR_INVALID, "need R >= 1, L >= 1, P >= 1");
+  if (L > (1 << 20)) return fail(PAL_ERR_UNSUPPORTED, "frame length %d exceeds 2^20", L);
+  Plan* pl = nullptr;
+  PAL_TRY(get_plan(2 * L - 1, L, 2 * L - 1, &pl));
+  void *sp = nullptr, *dq = nullptr, *stp = nullptr;
+  PAL_TRY(scratch(2, size_t(R) * pl->spec_stride() * sizeof(cd) + size_t(R) * sizeof(int), &sp));
+  int* nonzero = reinterpret_cast<int*>(static_cast<cd*>(sp) + size_t(R) * pl->spec_stride());
+  const int64_t ntr = (P + 1) / 2;
+  PAL_TRY(scratch(3, size_t(ntr) * sizeof(int4), &dq));
+  PAL_TRY(scratch(7, 64, &stp));
+  k_pairs_to_quads<<<dim3(unsigned((ntr + 255) / 256)), dim3(256), 0, stream>>>(d_pairs, P, R, static_cast<int4*>(dq), static_cast<int*>(stp));
+  PAL_HIP(hipGetLastError());
+  PAL_TRY(forward_spectra(*pl, d_rows, size_t(L), R, L, static_cast<cd*>(sp), nonzero));
+  return pair_correlations(*pl, static_cast<const cd*>(sp), R, static_cast<const int4*>(dq), P, L, prm, d_table, nullptr, nullptr, nonzero);
 }
 
 int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4* quads, int64_t npairs, int n2,
@@ -364,8 +484,8 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[0], 0));
     if (nslot == 3) PAL_HIP(hipStreamWaitEvent(stream3, ev_corr[0], 0));
   }
-  int64_t group = 0;
-  for (int64_t t0 = 0; t0 < ntr; t0 += chunk, ++group) {
+  // one launch group; a failure leaves through the common exit below (side streams joined, sampling gate restored)
+  auto run_group = [&](int64_t t0, int64_t group) -> int {
     const int G = int(ntr - t0 < chunk ? ntr - t0 : chunk);
     const int64_t p0 = 2 * t0;
     const int rows = int(npairs - p0 < 2 * G ? npairs - p0 : 2 * G);
@@ -409,6 +529,22 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     if (table && !fused)
       PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr, pon));
     if (split) PAL_HIP(hipEventRecord(ev_peaks[slot], stream2));
+    return PAL_OK;
+  };
+  int64_t group = 0;
+  for (int64_t t0 = 0; t0 < ntr; t0 += chunk, ++group) {
+    const int rc = run_group(t0, group);
+    if (rc != PAL_OK) {
+      // work may still be running on the side streams: nothing that follows (frees, reuse of the workspaces, the
+      // caller's next call) may overtake it
+      prof_gate = true;
+      const std::string keep = err;
+      (void)hipStreamSynchronize(stream);
+      (void)hipStreamSynchronize(stream2);
+      (void)hipStreamSynchronize(stream3);
+      err = keep;
+      return rc;
+    }
   }
   prof_gate = true;
   if (two || split) {   // whatever follows on `stream` (downloads, the RCCL gather) sees the finished table

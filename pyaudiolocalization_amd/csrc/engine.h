@@ -64,6 +64,7 @@ struct Plan {
   Conv fwd;         // forward:  lin inputs -> H outputs
   Conv inv;         // inverse:  n inputs  -> n outputs (two real sequences per complex transform)
   Pfa pfa;          // prime-factor route of the PHAT inverse when n splits (otherwise `inv` does it)
+  long long used = 0;   // Engine::plan_clock at the last get_plan (the cache evicts the least recently used plan)
   // elements per row of the spectra that forward_spectra writes and pair_correlations reads: the half spectrum, or
   // the permuted rows k1 <= (N1-1)/2 of the prime-factor layout
   size_t spec_stride() const { return pfa.on() ? size_t(pfa.rows()) * size_t(pfa.n2) : size_t(H); }
@@ -99,6 +100,10 @@ struct Engine {
     return int(g < 32 ? 32 : (g > 240 ? 240 : g));
   }
   std::map<std::tuple<int, int, int>, Plan> plans;   // (n, lin, nout) -> plan
+  struct XConv { Conv conv; long long used = 0; };
+  std::map<size_t, XConv> xconvs;                    // sequence length -> convolution of pal_xcorr_vs_ref
+  int max_plans = 32;                                // PAL_MAX_PLANS: bound of both caches (least recently used out first)
+  long long plan_clock = 0;
   cd* stage_tw[13] = {};                        // stage-major twiddles per log2 N
   cd* stage_twc[13] = {};                       // the same with a compact last stage (fft_core.h stage_twc_size)
   // growable device scratch
@@ -132,6 +137,9 @@ struct Engine {
   int pfa_pair_group(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, double* corr, size_t stride,
                      const int* zero_rows, hipStream_t on);
   int get_plan(int n, int lin, int nout, Plan** out);
+  void free_plan(Plan& pl);
+  int clear_plans();
+  int xcorr_conv(size_t len, Conv** out);
   int alloc_conv(Conv& c, size_t needed);   // geometry, tables and chirp-spectrum storage for >= `needed` points
   void free_conv(Conv& c);
   int build_conv(Conv& c, const cd* w, int n, int neg_count, int pos_count, bool conj_kernel, double extra_scale);
@@ -146,6 +154,8 @@ struct Engine {
   int pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4* quads, int64_t npairs, int n2,
                         const pal_phat_params& prm, pal_pair_record* table, int32_t* ksel_multi, double* corr_out,
                         const int* nonzero = nullptr);
+  int pairs_dev(const double* d_rows, int R, int L, const int32_t* d_pairs, int64_t P, const pal_phat_params& prm,
+                pal_pair_record* d_table);
   int peaks(const double* corr, size_t stride, int rows, int n, int n2, const pal_phat_params& prm,
             pal_pair_record* table, int32_t* ksel_multi, hipStream_t on);
   // the same in pieces, for the column pass that produces the streaming statistics itself (pfa_cols_stats.h):

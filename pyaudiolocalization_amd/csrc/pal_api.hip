@@ -107,6 +107,15 @@ static int check_status(Engine* e) {
       hipMemset(static_cast<int*>(e->ws[7]) + 1, 0, sizeof slow);
     }
   }
+  int in = 0;                                // word 2: input problems found by device-side checks
+  rc = e->check(hipMemcpy(&in, static_cast<int*>(e->ws[7]) + 2, sizeof in, hipMemcpyDeviceToHost), "status read");
+  if (rc != PAL_OK) return rc;
+  if (in) {
+    hipMemset(static_cast<int*>(e->ws[7]) + 2, 0, sizeof in);
+    if (in & 2) return e->fail(PAL_ERR_INVALID, "pair list references a row outside the frame batch");
+    return e->fail(PAL_ERR_INVALID, "non-finite sample (NaN or infinity) in a frame: the pair packed with that microphone's "
+                                    "pairs would be affected too, the table of this call is not valid");
+  }
   if (st) {
     hipMemset(e->ws[7], 0, sizeof st);
     return e->fail(PAL_ERR_INTERNAL, "peak selection: suppression chain exceeded the on-chip memo/stack (rows fell back to argmax)");
@@ -169,34 +178,22 @@ static int all_pairs_dev(Engine* e, const double* d_frames, int B, int M, int L,
   return e->pair_correlations(*pl, spectra, rows, static_cast<const int4*>(qp), np, L, *prm, d_table, nullptr, d_corr, nonzero);
 }
 
-// explicit pair list over R equal-length rows (host buffers): one-vs-many bootstrap batches, sparse pair sets
+// explicit pair list over R equal-length rows (host buffers): upload, then the device-resident form
 static int pairs_host(Engine* e, const double* rows_in, int R, int L, const int32_t* pairs, int64_t P,
                       const pal_phat_params* prm, pal_pair_record* table) {
   PAL_TRY(validate(e, prm));
   if (!rows_in || !pairs || !table) return e->fail(PAL_ERR_INVALID, "NULL buffer");
   if (R < 1 || L < 1 || P < 1) return e->fail(PAL_ERR_INVALID, "need R >= 1, L >= 1, P >= 1");
-  if (L > (1 << 20)) return e->fail(PAL_ERR_UNSUPPORTED, "frame length %d exceeds 2^20", L);
-  std::vector<int4> quads(size_t((P + 1) / 2), make_int4(0, 0, -1, -1));
-  for (int64_t k = 0; k < P; ++k) {
-    const int a = pairs[2 * k], b = pairs[2 * k + 1];
-    if (a < 0 || a >= R || b < 0 || b >= R) return e->fail(PAL_ERR_INVALID, "pair %lld references row outside 0..%d", (long long)k, R - 1);
-    int4& t = quads[size_t(k / 2)];
-    if (k & 1) { t.z = a; t.w = b; } else { t.x = a; t.y = b; }
-  }
-  Plan* pl = nullptr;
-  PAL_TRY(e->get_plan(2 * L - 1, L, 2 * L - 1, &pl));
-  void *df = nullptr, *sp = nullptr, *dt = nullptr, *dq = nullptr;
+  for (int64_t k = 0; k < 2 * P; ++k)
+    if (pairs[k] < 0 || pairs[k] >= R) return e->fail(PAL_ERR_INVALID, "pair %lld references row outside 0..%d", (long long)(k / 2), R - 1);
+  void *df = nullptr, *dt = nullptr, *dp = nullptr;
   PAL_TRY(e->scratch(4, size_t(R) * L * sizeof(double), &df));
-  PAL_TRY(e->scratch(2, size_t(R) * pl->spec_stride() * sizeof(cd) + size_t(R) * sizeof(int), &sp));
-  int* nonzero = reinterpret_cast<int*>(static_cast<cd*>(sp) + size_t(R) * pl->spec_stride());
   PAL_TRY(e->scratch(5, size_t(P) * sizeof(pal_pair_record), &dt));
-  PAL_TRY(e->scratch(3, quads.size() * sizeof(int4), &dq));
+  PAL_TRY(e->scratch(15, size_t(2 * P) * sizeof(int32_t), &dp));
   PAL_TRY(e->check(hipMemcpyAsync(df, rows_in, size_t(R) * L * sizeof(double), hipMemcpyHostToDevice, e->stream), "rows upload"));
-  PAL_TRY(e->check(hipMemcpyAsync(dq, quads.data(), quads.size() * sizeof(int4), hipMemcpyHostToDevice, e->stream), "pairs upload"));
+  PAL_TRY(e->check(hipMemcpyAsync(dp, pairs, size_t(2 * P) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream), "pairs upload"));
   PAL_TRY(e->check(hipStreamSynchronize(e->stream), "upload sync"));
-  PAL_TRY(e->forward_spectra(*pl, static_cast<const double*>(df), size_t(L), R, L, static_cast<cd*>(sp), nonzero));
-  PAL_TRY(e->pair_correlations(*pl, static_cast<const cd*>(sp), R, static_cast<const int4*>(dq), P, L, *prm,
-                               static_cast<pal_pair_record*>(dt), nullptr, nullptr, nonzero));
+  PAL_TRY(e->pairs_dev(static_cast<const double*>(df), R, L, static_cast<const int32_t*>(dp), P, *prm, static_cast<pal_pair_record*>(dt)));
   return e->check(hipMemcpyAsync(table, dt, size_t(P) * sizeof(pal_pair_record), hipMemcpyDeviceToHost, e->stream), "table download");
 }
 
@@ -252,6 +249,8 @@ int pal_create(int device, pal_handle* out) {
   if (env) e->fuse_peaks = atoi(env) != 0;
   env = getenv("PAL_PFA_SUB");
   if (env) e->pfa_sub = atoi(env);
+  env = getenv("PAL_MAX_PLANS");
+  if (env && atoi(env) >= 2) e->max_plans = atoi(env);
   *out = reinterpret_cast<pal_handle>(e);
   return PAL_OK;
 }
@@ -261,13 +260,7 @@ void pal_destroy(pal_handle h) {
   Engine* e = reinterpret_cast<Engine*>(h);
   hipSetDevice(e->device);
   pal_comm_destroy(h);
-  hipStreamSynchronize(e->stream);
-  for (auto& kv : e->plans) {
-    hipFree(kv.second.w);
-    e->free_conv(kv.second.fwd);
-    e->free_conv(kv.second.inv);
-    e->free_pfa(kv.second.pfa);
-  }
+  (void)e->clear_plans();                     // drains the three streams first
   for (cd* p : e->stage_tw) if (p) hipFree(p);
   for (cd* p : e->stage_twc) if (p) hipFree(p);
   for (void* p : e->ws) if (p) hipFree(p);
@@ -298,6 +291,11 @@ int pal_synchronize(pal_handle h) {
   return check_status(e);
 }
 
+int pal_clear_plans(pal_handle h) {
+  ENGINE(h);
+  return e->clear_plans();
+}
+
 int pal_set_chunk(pal_handle h, int chunk) {
   ENGINE(h);
   if (chunk < 0 || chunk > 4096) return e->fail(PAL_ERR_INVALID, "chunk %d outside 0..4096", chunk);
@@ -314,6 +312,8 @@ int pal_device_alloc(pal_handle h, size_t bytes, void** dptr) {
 int pal_device_free(pal_handle h, void* dptr) {
   ENGINE(h);
   PAL_TRY(e->check(hipStreamSynchronize(e->stream), "stream sync"));
+  PAL_TRY(e->check(hipStreamSynchronize(e->stream2), "stream sync"));
+  PAL_TRY(e->check(hipStreamSynchronize(e->stream3), "stream sync"));
   return e->check(hipFree(dptr), "hipFree");
 }
 
@@ -360,6 +360,14 @@ int pal_gcc_phat_pairs(pal_handle h, const double* rows, int R, int L, const int
   ENGINE(h);
   PAL_TRY(pairs_host(e, rows, R, L, pairs, P, prm, table));
   return pal_synchronize(h);
+}
+
+int pal_gcc_phat_pairs_dev(pal_handle h, const double* d_rows, int R, int L, const int32_t* d_pairs, int64_t P,
+                           const pal_phat_params* prm, pal_pair_record* d_table) {
+  ENGINE(h);
+  PAL_TRY(validate(e, prm));
+  if (!d_rows || !d_pairs || !d_table) return e->fail(PAL_ERR_INVALID, "NULL buffer");
+  return e->pairs_dev(d_rows, R, L, d_pairs, P, *prm, d_table);
 }
 
 static int single_pair(Engine* e, const double* sig1, int n1, const double* sig2, int n2, const pal_phat_params* prm,

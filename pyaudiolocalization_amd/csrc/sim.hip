@@ -108,6 +108,43 @@ __global__ __launch_bounds__(256) void k_norm_compress(const double* in, size_t 
   }
 }
 
+// Per-mic power-of-two rescale of the path gains: gains reach 1e-63 and two mics share one complex
+// transform, so a mic 1e16 times weaker than its partner would drown in the partner's rounding error.  Scaling a row by
+// 2^-e is exact and cancels bit for bit in normalize_signal (x / max|x|).  One lane per row (K is a handful of paths).
+__global__ __launch_bounds__(256) void k_gain_rescale(const double* in, double* out, int rows, int K) {   // (in place when in == out)
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  double top = 0;
+  for (int p = 0; p < K; ++p) top = fmax(top, fabs(in[size_t(r) * K + p]));
+  const bool scale = top > 0 && isfinite(top);
+  const int ex = scale ? ilogb(top) : 0;
+  for (int p = 0; p < K; ++p) out[size_t(r) * K + p] = scale ? ldexp(in[size_t(r) * K + p], -ex) : in[size_t(r) * K + p];
+}
+
+// np.sum(sig ** 2) per row (utils.py:413): only the ORDER of the rows' energies matters (argmax picks the reference
+// microphone); identical rows give identical sums, so np.argmax's first-of-equals rule carries over.
+__global__ __launch_bounds__(256) void k_row_energy(const double* __restrict__ x, size_t stride, int N, double* __restrict__ energy) {
+  __shared__ double rd[4];
+  const double* r = x + size_t(blockIdx.x) * stride;
+  double acc = 0;
+  for (int i = threadIdx.x; i < N; i += kLanes) acc = __builtin_fma(r[i], r[i], acc);
+  acc = block_sum(acc, rd, threadIdx.x);
+  if (threadIdx.x == 0) energy[blockIdx.x] = acc;
+}
+
+// utils.py:448-456: np.pad(sig, (pad_left, 0)) then right-pad to the common length: out[row][pad + i] = in[row][i]
+__global__ __launch_bounds__(256) void k_align_rows(const double* __restrict__ in, size_t istride, int N, const int32_t* __restrict__ pad,
+                                                    double* __restrict__ out, size_t ostride, int Lout) {
+  const int row = blockIdx.y;
+  const int p = pad[row];
+  const double* src = in + size_t(row) * istride;
+  double* dst = out + size_t(row) * ostride;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Lout; i += gridDim.x * 256) {
+    const int j = i - p;
+    dst[i] = j >= 0 && j < N ? src[j] : 0.0;
+  }
+}
+
 // ------------------------------------------------------------------ filtfilt
 __device__ __forceinline__ double odd_ext(const double* x, int N, int edge, int i) {
   if (i < edge) return 2 * x[0] - x[edge - i];
@@ -291,6 +328,69 @@ static int simulate_dev(Engine* e, const double* d_base, int bases, int nbase, d
   return PAL_OK;
 }
 
+
+// filtfilt of rows[R][N] that already sit in HBM (b | a | zi normalised by a[0] are uploaded: 3 K doubles)
+static int filtfilt_dev(Engine* e, const double* b, int nb, const double* a, int na, const double* zi, const double* d_x, int R,
+                        int N, double* d_y) {
+  if (!b || !a || !zi || !d_x || !d_y || nb < 1 || na < 1 || R < 1) return e->fail(PAL_ERR_INVALID, "bad filtfilt arguments");
+  const int K = nb > na ? nb : na;
+  if (K < 2 || K > 512) return e->fail(PAL_ERR_UNSUPPORTED, "filter length %d outside 2..512", K);
+  const int edge = 3 * K;
+  if (N <= edge) return e->fail(PAL_ERR_INVALID, "The length of the input vector x must be greater than padlen, which is %d.", edge);
+  if (a[0] == 0) return e->fail(PAL_ERR_INVALID, "a[0] must be non-zero");
+  std::vector<double> coef(size_t(3 * K), 0.0);          // b | a | zi, normalised by a[0] like scipy's lfilter
+  for (int q = 0; q < nb; ++q) coef[q] = b[q] / a[0];
+  for (int q = 0; q < na; ++q) coef[K + q] = a[q] / a[0];
+  for (int q = 0; q < K - 1; ++q) coef[2 * K + q] = zi[q];
+  void *dc = nullptr, *dt = nullptr;
+  PAL_TRY(e->scratch(3, coef.size() * sizeof(double), &dc));
+  PAL_TRY(e->scratch(1, size_t(R) * (N + 2 * edge) * sizeof(double), &dt));
+  PAL_TRY(e->check(hipMemcpyAsync(dc, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, e->stream), "upload"));
+  PAL_TRY(e->check(hipStreamSynchronize(e->stream), "upload sync"));   // `coef` is host memory
+  const double* cb = static_cast<double*>(dc);
+  {
+    ProfScope ps(e, "k_filtfilt");
+    const dim3 grid((R + 63) / 64);
+    if (K == 11) k_filtfilt<11><<<grid, dim3(64), 0, e->stream>>>(d_x, R, N, cb, cb + K, cb + 2 * K, K, static_cast<double*>(dt), d_y);
+    else k_filtfilt<0><<<grid, dim3(64), 0, e->stream>>>(d_x, R, N, cb, cb + K, cb + 2 * K, K, static_cast<double*>(dt), d_y);
+  }
+  return e->check(hipGetLastError(), "k_filtfilt");
+}
+
+// full cross-correlation of rows[R][N] against row ref_idx (all in HBM): kpk / win5 / pkabs land in device arrays of R entries
+static int xcorr_dev(Engine* e, const double* x, int R, int N, int ref_idx, int32_t* dk, double* dw, double* dp) {
+  if (N > (1 << 20)) return e->fail(PAL_ERR_UNSUPPORTED, "signal longer than 2^20 samples");
+  const int len = 2 * N - 1;
+  // geometry, tables and kernel-spectrum storage of the convolution are kept per length (sync runs once per frame in
+  // the streaming configuration; hipMalloc / hipFree per call cost more than the correlations)
+  Conv* cp = nullptr;
+  PAL_TRY(e->xcorr_conv(size_t(len), &cp));
+  const Conv& c = *cp;
+  void *wsp = nullptr, *dcor = nullptr;
+  RefLoader rl{x + size_t(ref_idx) * N, N};
+  PAL_TRY(launch_cols_fwd(e, c, 1, rl, c.chat));
+  PAL_TRY(launch_rows(e, c, 1, c.chat, false, 1.0 / double(c.M())));
+  PAL_TRY(e->scratch(0, size_t(e->chunk) * c.M() * sizeof(cd), &wsp));
+  const size_t stride = size_t(len) + 1;
+  PAL_TRY(e->scratch(1, size_t(2 * e->chunk) * stride * sizeof(double), &dcor));
+  const int ntr = (R + 1) / 2;
+  for (int t0 = 0; t0 < ntr; t0 += e->chunk) {
+    const int G = ntr - t0 < e->chunk ? ntr - t0 : e->chunk;
+    const int r0 = 2 * t0, nrows = R - r0 < 2 * G ? R - r0 : 2 * G;
+    RowPairLoader ld{x + size_t(r0) * N, N, R - r0};
+    PlainStorer st{static_cast<double*>(dcor), stride, len};
+    PAL_TRY(launch_cols_fwd(e, c, G, ld, static_cast<cd*>(wsp)));
+    PAL_TRY(launch_rows(e, c, G, static_cast<cd*>(wsp), true, 1.0));
+    PAL_TRY(launch_cols_inv(e, c, G, static_cast<cd*>(wsp), st));
+    {
+      ProfScope ps(e, "k_xcorr_peak");
+      k_xcorr_peak<<<dim3(nrows), dim3(kLanes), 0, e->stream>>>(static_cast<double*>(dcor), stride, len, dk + r0, dw + size_t(r0) * 5, dp + r0);
+    }
+    PAL_TRY(e->check(hipGetLastError(), "k_xcorr_peak"));
+  }
+  return PAL_OK;
+}
+
 }  // namespace pal
 
 using namespace pal;
@@ -322,19 +422,10 @@ int pal_simulate_multipath(pal_handle h, const double* base, int B, int nbase, d
     if ((rc = e->scratch(6, size_t(rows) * out_len * sizeof(double), &dout)) != PAL_OK) break;
     if ((rc = e->check(hipMemcpyAsync(db, base, size_t(B) * nbase * sizeof(double), hipMemcpyHostToDevice, e->stream), "upload")) != PAL_OK) break;
     if ((rc = e->check(hipMemcpyAsync(dd, delays, size_t(rows) * K * sizeof(double), hipMemcpyHostToDevice, e->stream), "upload")) != PAL_OK) break;
-    // Per-mic power-of-two rescale: path gains reach 1e-63 and two mics share one complex
-    // transform, so a mic 1e16 times weaker than its partner would drown in the partner's rounding
-    // error.  Scaling a row by 2^-e is exact and cancels bit for bit in normalize_signal (x / max|x|).
-    std::vector<double> scaled(gains, gains + size_t(rows) * K);
-    for (int r = 0; r < rows; ++r) {
-      double top = 0;
-      for (int p = 0; p < K; ++p) top = std::fmax(top, std::fabs(scaled[size_t(r) * K + p]));
-      if (top > 0 && std::isfinite(top)) {
-        const int ex = std::ilogb(top);
-        for (int p = 0; p < K; ++p) scaled[size_t(r) * K + p] = std::ldexp(scaled[size_t(r) * K + p], -ex);
-      }
-    }
-    if ((rc = e->check(hipMemcpyAsync(dg, scaled.data(), size_t(rows) * K * sizeof(double), hipMemcpyHostToDevice, e->stream), "upload")) != PAL_OK) break;
+    // per-mic power-of-two rescale of the gains: k_gain_rescale, in place
+    if ((rc = e->check(hipMemcpyAsync(dg, gains, size_t(rows) * K * sizeof(double), hipMemcpyHostToDevice, e->stream), "upload")) != PAL_OK) break;
+    k_gain_rescale<<<dim3((rows + 255) / 256), dim3(256), 0, e->stream>>>(static_cast<double*>(dg), static_cast<double*>(dg), rows, K);
+    if ((rc = e->check(hipGetLastError(), "k_gain_rescale")) != PAL_OK) break;
     if ((rc = e->check(hipStreamSynchronize(e->stream), "upload sync")) != PAL_OK) break;
     rc = simulate_dev(e, static_cast<double*>(db), B, nbase, fs, N, static_cast<double*>(dd), static_cast<double*>(dg), rows, M,
                       K, out_len, true, true, static_cast<double*>(dout));
@@ -384,37 +475,12 @@ int pal_normalize_compress(pal_handle h, const double* rows_in, int R, int N, in
 int pal_filtfilt(pal_handle h, const double* b, int nb, const double* a, int na, const double* zi, const double* rows_in,
                  int R, int N, double* out) {
   ENGINE(h);
-  if (!b || !a || !zi || !rows_in || !out || nb < 1 || na < 1 || R < 1) return e->fail(PAL_ERR_INVALID, "bad filtfilt arguments");
-  const int K = nb > na ? nb : na;
-  if (K < 2 || K > 512) return e->fail(PAL_ERR_UNSUPPORTED, "filter length %d outside 2..512", K);
-  const int edge = 3 * K;
-  if (N <= edge) return e->fail(PAL_ERR_INVALID, "The length of the input vector x must be greater than padlen, which is %d.", edge);
-  if (a[0] == 0) return e->fail(PAL_ERR_INVALID, "a[0] must be non-zero");
-  std::vector<double> coef(size_t(3 * K), 0.0);          // b | a | zi, normalised by a[0] like scipy's lfilter
-  for (int q = 0; q < nb; ++q) coef[q] = b[q] / a[0];
-  for (int q = 0; q < na; ++q) coef[K + q] = a[q] / a[0];
-  for (int q = 0; q < K - 1; ++q) coef[2 * K + q] = zi[q];
-  void *dc = nullptr, *dx = nullptr, *dt = nullptr, *dy = nullptr;
-  PAL_TRY(e->scratch(3, coef.size() * sizeof(double), &dc));
+  if (!rows_in || !out || R < 1 || N < 1) return e->fail(PAL_ERR_INVALID, "bad filtfilt arguments");
+  void *dx = nullptr, *dy = nullptr;
   PAL_TRY(e->scratch(4, size_t(R) * N * sizeof(double), &dx));
-  PAL_TRY(e->scratch(1, size_t(R) * (N + 2 * edge) * sizeof(double), &dt));
   PAL_TRY(e->scratch(6, size_t(R) * N * sizeof(double), &dy));
-  UP(dc, coef.data(), coef.size() * sizeof(double));
   UP(dx, rows_in, size_t(R) * N * sizeof(double));
-  PAL_TRY(e->check(hipStreamSynchronize(e->stream), "upload sync"));
-  const double* cb = static_cast<double*>(dc);
-  {
-    ProfScope ps(e, "k_filtfilt");
-    const dim3 grid((R + 63) / 64);
-    if (K == 11) {
-      k_filtfilt<11><<<grid, dim3(64), 0, e->stream>>>(static_cast<double*>(dx), R, N, cb, cb + K, cb + 2 * K, K,
-                                                      static_cast<double*>(dt), static_cast<double*>(dy));
-    } else {
-      k_filtfilt<0><<<grid, dim3(64), 0, e->stream>>>(static_cast<double*>(dx), R, N, cb, cb + K, cb + 2 * K, K,
-                                                     static_cast<double*>(dt), static_cast<double*>(dy));
-    }
-  }
-  PAL_TRY(e->check(hipGetLastError(), "k_filtfilt"));
+  PAL_TRY(filtfilt_dev(e, b, nb, a, na, zi, static_cast<double*>(dx), R, N, static_cast<double*>(dy)));
   DOWN(out, dy, size_t(R) * N * sizeof(double));
   return pal_synchronize(h);
 }
@@ -440,51 +506,112 @@ int pal_xcorr_vs_ref(pal_handle h, const double* rows_in, int R, int N, int ref_
   ENGINE(h);
   if (!rows_in || !kpk || !win5 || !pkabs || R < 1 || N < 1 || ref_idx < 0 || ref_idx >= R)
     return e->fail(PAL_ERR_INVALID, "bad xcorr arguments");
-  if (N > (1 << 20)) return e->fail(PAL_ERR_UNSUPPORTED, "signal longer than 2^20 samples");
-  const int len = 2 * N - 1;
-  void *dx = nullptr, *wsp = nullptr, *dcor = nullptr, *dres = nullptr;
+  void *dx = nullptr, *dres = nullptr;
   PAL_TRY(e->scratch(4, size_t(R) * N * sizeof(double), &dx));
   UP(dx, rows_in, size_t(R) * N * sizeof(double));
-  const double* x = static_cast<double*>(dx);
-  Conv c;
-  PAL_TRY(e->alloc_conv(c, size_t(len)));
+  // result block: kpk[R] (int32, padded to 16 bytes) | win5[R][5] | pkabs[R]
+  const size_t off_d = (size_t(R) * sizeof(int32_t) + 15) & ~size_t(15);
+  PAL_TRY(e->scratch(5, off_d + size_t(R) * 6 * sizeof(double), &dres));
+  int32_t* dk = static_cast<int32_t*>(dres);
+  double* dw = reinterpret_cast<double*>(static_cast<char*>(dres) + off_d);
+  double* dp = dw + size_t(R) * 5;
+  int rc = xcorr_dev(e, static_cast<const double*>(dx), R, N, ref_idx, dk, dw, dp);
+  if (rc == PAL_OK) rc = e->check(hipMemcpyAsync(kpk, dk, size_t(R) * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream), "download");
+  if (rc == PAL_OK) rc = e->check(hipMemcpyAsync(win5, dw, size_t(R) * 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream), "download");
+  if (rc == PAL_OK) rc = e->check(hipMemcpyAsync(pkabs, dp, size_t(R) * sizeof(double), hipMemcpyDeviceToHost, e->stream), "download");
+  if (rc != PAL_OK) { (void)hipStreamSynchronize(e->stream); return rc; }
+  PAL_TRY(pal_synchronize(h));
+  if (refpk) *refpk = pkabs[ref_idx];
+  return PAL_OK;
+}
+
+/* ---- device-resident forms (streaming configuration: simulate -> synchronise -> prefilter -> pairs without host copies
+ *      of the waveforms; the host supplies path tables and filter coefficients and reads back a few numbers per row) ---- */
+
+int pal_simulate_multipath_dev(pal_handle h, const double* d_base, int B, int nbase, double fs, int total_samples,
+                               const double* d_delays, const double* d_gains, int M, int K, int trim_len, double* d_out) {
+  ENGINE(h);
+  if (!d_base || !d_delays || !d_gains || !d_out) return e->fail(PAL_ERR_INVALID, "NULL buffer");
+  if (B < 1 || M < 1 || K < 1 || nbase < 1 || !(fs > 0)) return e->fail(PAL_ERR_INVALID, "bad simulation geometry");
+  const int N = total_samples;
+  const int out_len = trim_len > 0 && trim_len < N ? trim_len : N;
+  const int rows = B * M;
+  void* dg = nullptr;
+  PAL_TRY(e->scratch(5, size_t(rows) * K * sizeof(double), &dg));
+  k_gain_rescale<<<dim3((rows + 255) / 256), dim3(256), 0, e->stream>>>(d_gains, static_cast<double*>(dg), rows, K);
+  PAL_TRY(e->check(hipGetLastError(), "k_gain_rescale"));
+  return simulate_dev(e, d_base, B, nbase, fs, N, d_delays, static_cast<double*>(dg), rows, M, K, out_len, true, true, d_out);
+}
+
+int pal_filtfilt_dev(pal_handle h, const double* b, int nb, const double* a, int na, const double* zi, const double* d_rows,
+                     int R, int N, double* d_out) {
+  ENGINE(h);
+  return filtfilt_dev(e, b, nb, a, na, zi, d_rows, R, N, d_out);
+}
+
+int pal_wiener3_dev(pal_handle h, const double* d_rows, int R, int N, double* d_out) {
+  ENGINE(h);
+  if (!d_rows || !d_out || R < 1 || N < 1) return e->fail(PAL_ERR_INVALID, "bad wiener arguments");
+  {
+    ProfScope ps(e, "k_wiener3");
+    k_wiener3<<<dim3(R), dim3(kLanes), 0, e->stream>>>(d_rows, d_out, N);
+  }
+  return e->check(hipGetLastError(), "k_wiener3");
+}
+
+int pal_sync_measure_dev(pal_handle h, const double* d_rows, int B, int M, int N, int32_t* ref_idx, int32_t* kpk,
+                         double* win5, double* pkabs, double* refpk) {
+  ENGINE(h);
+  if (!d_rows || !ref_idx || !kpk || !win5 || !pkabs || B < 1 || M < 1 || N < 1) return e->fail(PAL_ERR_INVALID, "bad sync arguments");
+  const int R = B * M;
+  // energies of every row -> the reference microphone of each frame (np.argmax: first of equals)
+  void* de = nullptr;
+  PAL_TRY(e->scratch(6, size_t(R) * sizeof(double), &de));
+  k_row_energy<<<dim3(R), dim3(kLanes), 0, e->stream>>>(d_rows, size_t(N), N, static_cast<double*>(de));
+  PAL_TRY(e->check(hipGetLastError(), "k_row_energy"));
+  std::vector<double> en(size_t(R), 0.0);
+  PAL_TRY(e->check(hipMemcpyAsync(en.data(), de, size_t(R) * sizeof(double), hipMemcpyDeviceToHost, e->stream), "download"));
+  PAL_TRY(e->check(hipStreamSynchronize(e->stream), "energy sync"));
+  for (int b = 0; b < B; ++b) {
+    int best = 0;
+    for (int m = 1; m < M; ++m)
+      if (en[size_t(b) * M + m] > en[size_t(b) * M + best]) best = m;      // (NaN never wins: np.argmax would return the NaN row -
+    for (int m = 0; m < M; ++m)                                            //  checked here)
+      if (en[size_t(b) * M + m] != en[size_t(b) * M + m]) { best = m; break; }
+    ref_idx[b] = best;
+  }
+  // result block for all frames: kpk[R] | win5[R][5] | pkabs[R]
+  void* dres = nullptr;
+  const size_t off_d = (size_t(R) * sizeof(int32_t) + 15) & ~size_t(15);
+  PAL_TRY(e->scratch(5, off_d + size_t(R) * 6 * sizeof(double), &dres));
+  int32_t* dk = static_cast<int32_t*>(dres);
+  double* dw = reinterpret_cast<double*>(static_cast<char*>(dres) + off_d);
+  double* dp = dw + size_t(R) * 5;
   int rc = PAL_OK;
-  do {
-    RefLoader rl{x + size_t(ref_idx) * N, N};
-    if ((rc = launch_cols_fwd(e, c, 1, rl, c.chat)) != PAL_OK) break;
-    if ((rc = launch_rows(e, c, 1, c.chat, false, 1.0 / double(c.M()))) != PAL_OK) break;
-    if ((rc = e->scratch(0, size_t(e->chunk) * c.M() * sizeof(cd), &wsp)) != PAL_OK) break;
-    const size_t stride = size_t(len) + 1;
-    if ((rc = e->scratch(1, size_t(2 * e->chunk) * stride * sizeof(double), &dcor)) != PAL_OK) break;
-    if ((rc = e->scratch(5, size_t(R + 1) * (sizeof(int32_t) + 6 * sizeof(double)), &dres)) != PAL_OK) break;
-    int32_t* dk = static_cast<int32_t*>(dres);
-    double* dw = reinterpret_cast<double*>(static_cast<char*>(dres) + ((size_t(R + 1) * sizeof(int32_t) + 15) & ~size_t(15)));
-    double* dp = dw + size_t(R + 1) * 5;
-    const int ntr = (R + 1) / 2;
-    for (int t0 = 0; t0 < ntr && rc == PAL_OK; t0 += e->chunk) {
-      const int G = ntr - t0 < e->chunk ? ntr - t0 : e->chunk;
-      const int r0 = 2 * t0, nrows = R - r0 < 2 * G ? R - r0 : 2 * G;
-      RowPairLoader ld{x + size_t(r0) * N, N, R - r0};
-      PlainStorer st{static_cast<double*>(dcor), stride, len};
-      if ((rc = launch_cols_fwd(e, c, G, ld, static_cast<cd*>(wsp))) != PAL_OK) break;
-      if ((rc = launch_rows(e, c, G, static_cast<cd*>(wsp), true, 1.0)) != PAL_OK) break;
-      if ((rc = launch_cols_inv(e, c, G, static_cast<cd*>(wsp), st)) != PAL_OK) break;
-      {
-        ProfScope ps(e, "k_xcorr_peak");
-        k_xcorr_peak<<<dim3(nrows), dim3(kLanes), 0, e->stream>>>(static_cast<double*>(dcor), stride, len, dk + r0, dw + size_t(r0) * 5, dp + r0);
-      }
-      rc = e->check(hipGetLastError(), "k_xcorr_peak");
-    }
-    if (rc != PAL_OK) break;
-    if ((rc = e->check(hipMemcpyAsync(kpk, dk, size_t(R) * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream), "download")) != PAL_OK) break;
-    if ((rc = e->check(hipMemcpyAsync(win5, dw, size_t(R) * 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream), "download")) != PAL_OK) break;
-    if ((rc = e->check(hipMemcpyAsync(pkabs, dp, size_t(R) * sizeof(double), hipMemcpyDeviceToHost, e->stream), "download")) != PAL_OK) break;
-    rc = pal_synchronize(h);
-  } while (0);
-  (void)hipStreamSynchronize(e->stream);
-  e->free_conv(c);
-  if (rc == PAL_OK && refpk) *refpk = pkabs[ref_idx];
-  return rc;
+  for (int b = 0; b < B && rc == PAL_OK; ++b)     // (the kernel spectrum is the frame's own reference row: one convolution set-up per frame)
+    rc = xcorr_dev(e, d_rows + size_t(b) * M * N, M, N, ref_idx[b], dk + size_t(b) * M, dw + size_t(b) * M * 5, dp + size_t(b) * M);
+  if (rc == PAL_OK) rc = e->check(hipMemcpyAsync(kpk, dk, size_t(R) * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream), "download");
+  if (rc == PAL_OK) rc = e->check(hipMemcpyAsync(win5, dw, size_t(R) * 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream), "download");
+  if (rc == PAL_OK) rc = e->check(hipMemcpyAsync(pkabs, dp, size_t(R) * sizeof(double), hipMemcpyDeviceToHost, e->stream), "download");
+  if (rc != PAL_OK) { (void)hipStreamSynchronize(e->stream); return rc; }
+  PAL_TRY(pal_synchronize(h));
+  if (refpk)
+    for (int b = 0; b < B; ++b) refpk[b] = pkabs[size_t(b) * M + ref_idx[b]];
+  return PAL_OK;
+}
+
+int pal_align_rows_dev(pal_handle h, const double* d_rows, int R, int N, const int32_t* pad_left, int Lout, double* d_out) {
+  ENGINE(h);
+  if (!d_rows || !pad_left || !d_out || R < 1 || N < 1 || Lout < N) return e->fail(PAL_ERR_INVALID, "bad align arguments");
+  for (int r = 0; r < R; ++r)
+    if (pad_left[r] < 0 || pad_left[r] + N > Lout) return e->fail(PAL_ERR_INVALID, "pad %d of row %d does not fit %d samples", pad_left[r], r, Lout);
+  void* dp = nullptr;
+  PAL_TRY(e->scratch(3, size_t(R) * sizeof(int32_t), &dp));
+  PAL_TRY(e->check(hipMemcpyAsync(dp, pad_left, size_t(R) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream), "upload"));
+  PAL_TRY(e->check(hipStreamSynchronize(e->stream), "upload sync"));   // `pad_left` is host memory
+  const unsigned gx = unsigned((Lout + 255) / 256 < 64 ? (Lout + 255) / 256 : 64);
+  k_align_rows<<<dim3(gx, unsigned(R)), dim3(256), 0, e->stream>>>(d_rows, size_t(N), N, static_cast<const int32_t*>(dp), d_out, size_t(Lout), Lout);
+  return e->check(hipGetLastError(), "k_align_rows");
 }
 
 }  // extern "C"

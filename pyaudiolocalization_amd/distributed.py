@@ -48,6 +48,44 @@ def gather_tables_torch(local: np.ndarray, total_frames: int, rank: int, world: 
     return np.concatenate(parts, axis=0)
 
 
+def gather_blocks_torch(local: np.ndarray, sizes: Sequence[int]) -> np.ndarray:
+    """All-gather of per-rank record blocks local[sizes[rank]] (1-D, structured RECORD rows) of unequal size: every rank
+    pads to the largest block; the concatenation in rank order is returned on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = len(sizes)
+    padded = np.zeros(max(sizes), dtype=RECORD)
+    padded[: local.shape[0]] = local
+    send = torch.from_numpy(padded.view(np.uint8).reshape(-1).copy())
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    return np.concatenate([r.numpy().view(RECORD)[: sizes[k]] for k, r in enumerate(recv)])
+
+
+def shard_pairs(mics: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [start, stop) of the ordered pair list (row-major i<j, main.py:202-203) owned by ``rank`` when ONE
+    frame is split over the GPUs (configuration C4: 256 microphones, 32 640 pairs -> 4080 per GPU on 8)."""
+    return shard_range(mics * (mics - 1) // 2, rank, world)
+
+
+def sharded_pair_table(frame: np.ndarray, rank: int, world: int, compute_block: Callable[[np.ndarray, np.ndarray], np.ndarray],
+                       gather=gather_blocks_torch) -> np.ndarray:
+    """Single large frame[M][L]: every rank holds the whole frame (the spectra are recomputed locally - cheaper than
+    moving them: 256 forward transforms against 4080 pair transforms per rank), computes the rows of its own block of the
+    pair list with ``compute_block(frame, pairs[start:stop])`` and ONE gather assembles table[P] on every rank."""
+    from .engine import pair_list
+    m = frame.shape[0]
+    pairs = pair_list(m)
+    sizes = [shard_pairs(m, r, world)[1] - shard_pairs(m, r, world)[0] for r in range(world)]
+    lo, hi = shard_pairs(m, rank, world)
+    if hi <= lo:
+        raise ValueError("more ranks than pairs")
+    local = compute_block(frame, pairs[lo:hi])
+    if local.shape != (hi - lo,):
+        raise ValueError("compute_block must return one record per pair of the block")
+    return gather(local, sizes)
+
+
 def gather_tables_rccl(engine, d_local: int, d_all: int, frames_per_rank: int, pairs: int) -> None:
     """One ncclAllGather of equal-size device tables (frames_per_rank * pairs records per rank)."""
     engine.all_gather_dev(d_local, d_all, frames_per_rank * pairs * RECORD.itemsize)

@@ -83,6 +83,10 @@ class Engine:
     def set_chunk(self, chunk: int) -> None:
         self._check(self._lib.pal_set_chunk(self._h, int(chunk)))
 
+    def clear_plans(self) -> None:
+        """Drop every cached transform plan (they are rebuilt on next use; the cache is bounded anyway)."""
+        self._check(self._lib.pal_clear_plans(self._h))
+
     def pair_group_size(self, length: int) -> int:
         """Packed transforms (two pairs each) per launch group of the all-pairs pipeline for frames of `length` samples."""
         g = C.c_int32()
@@ -155,6 +159,11 @@ class Engine:
         self._check(self._lib.pal_gcc_phat_pairs(self._h, x.ctypes.data, x.shape[0], x.shape[1], pr.ctypes.data, pr.shape[0],
                                                  C.byref(prm), table.ctypes.data))
         return table
+
+    def gcc_phat_pairs_dev(self, d_rows: int, r: int, length: int, d_pairs: int, p: int, prm: PhatParams, d_table: int) -> None:
+        """Asynchronous: rows[R][L], pairs[P][2] (int32) and table[P] stay in HBM (a rank's block of a large frame's pair list)."""
+        self._check(self._lib.pal_gcc_phat_pairs_dev(self._h, C.c_void_p(d_rows), int(r), int(length), C.c_void_p(d_pairs), int(p),
+                                                     C.byref(prm), C.c_void_p(d_table)))
 
     def phat_correlation(self, sig1, sig2) -> np.ndarray:
         a, b = f64(sig1), f64(sig2)
@@ -257,6 +266,39 @@ class Engine:
         self._check(self._lib.pal_xcorr_vs_ref(self._h, x.ctypes.data, r, x.shape[1], int(ref_idx), kpk.ctypes.data,
                                                win.ctypes.data, pk.ctypes.data, C.byref(ref)))
         return kpk, win, pk, ref.value
+
+    # ---- device-resident stage chain (main.py:165-204 without host copies of the waveforms) ------
+    def simulate_multipath_dev(self, d_base: int, b: int, nbase: int, fs: float, total_samples: int, d_delays: int, d_gains: int,
+                               m: int, k: int, trim_len: int, d_out: int) -> None:
+        self._check(self._lib.pal_simulate_multipath_dev(self._h, C.c_void_p(d_base), int(b), int(nbase), float(fs), int(total_samples),
+                                                         C.c_void_p(d_delays), C.c_void_p(d_gains), int(m), int(k), int(trim_len),
+                                                         C.c_void_p(d_out)))
+
+    def sync_measure_dev(self, d_rows: int, b: int, m: int, n: int):
+        """Per frame: reference microphone (highest energy) and the cross-correlation measurements of every row against it
+        -> (ref_idx[B], kpk[B][M], win5[B][M][5], pkabs[B][M], refpk[B]) on the host (a few numbers per row)."""
+        ref = np.zeros(b, dtype=np.int32)
+        kpk = np.zeros((b, m), dtype=np.int32)
+        win = np.zeros((b, m, 5))
+        pk = np.zeros((b, m))
+        refpk = np.zeros(b)
+        self._check(self._lib.pal_sync_measure_dev(self._h, C.c_void_p(d_rows), int(b), int(m), int(n), ref.ctypes.data, kpk.ctypes.data,
+                                                   win.ctypes.data, pk.ctypes.data, refpk.ctypes.data))
+        return ref, kpk, win, pk, refpk
+
+    def align_rows_dev(self, d_rows: int, r: int, n: int, pad_left, lout: int, d_out: int) -> None:
+        pads = np.ascontiguousarray(pad_left, dtype=np.int32)
+        if pads.shape != (r,):
+            raise ValueError("one pad per row")
+        self._check(self._lib.pal_align_rows_dev(self._h, C.c_void_p(d_rows), int(r), int(n), pads.ctypes.data, int(lout), C.c_void_p(d_out)))
+
+    def filtfilt_dev(self, b, a, zi, d_rows: int, r: int, n: int, d_out: int) -> None:
+        b, a, zi = f64(b), f64(a), f64(zi)
+        self._check(self._lib.pal_filtfilt_dev(self._h, b.ctypes.data, b.shape[0], a.ctypes.data, a.shape[0], zi.ctypes.data,
+                                               C.c_void_p(d_rows), int(r), int(n), C.c_void_p(d_out)))
+
+    def wiener3_dev(self, d_rows: int, r: int, n: int, d_out: int) -> None:
+        self._check(self._lib.pal_wiener3_dev(self._h, C.c_void_p(d_rows), int(r), int(n), C.c_void_p(d_out)))
 
     # ---- multi-GPU ---------------------------------------------------------------------
     @staticmethod

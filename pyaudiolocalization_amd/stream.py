@@ -1,0 +1,99 @@
+"""Device-resident stage chain of localize_sound_source for many frames (main.py:165-204): simulate -> synchronise ->
+prefilter -> all pairs with every waveform staying in HBM.  This is the streaming configuration of BASELINE.json
+(64 microphones x 1024 frames of 0.25 s, multipath simulation on): the host supplies the base signals, the per-frame
+path tables and the filter design, reads back five numbers per row for the synchronisation (the 5-point spline and the
+integer pads of utils.py:428-451 are host scalar work) and receives the TDOA tables.
+
+Frame lengths follow the reference: the simulated length int((duration + longest path delay) * fs) (main.py:102) and the
+synchronised length N + (max shift - min shift) (utils.py:448-456) differ from frame to frame, and with them
+the exact DFT lengths.  Frames are therefore grouped by those lengths and every group runs as one batched engine call;
+the results are the staged host path's (simulate_signals_with_multipath -> synchronize_signals_improved ->
+noise_reduction -> pair table), bit for bit - tests/test_gpu_stream.py."""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._ffi import RECORD
+from .engine import Engine, default_engine, make_params
+from .signal_processing import _filter_design
+from .utils import sync_shifts_from_measurements
+
+
+def tdoa_stream(bases: Sequence[np.ndarray], delays: Sequence[np.ndarray], gains: Sequence[np.ndarray], fs: float,
+                totals: Sequence[int], trim_len: int, filter_method: str = "butterworth",
+                max_expected_delay: Optional[float] = None, engine: Optional[Engine] = None,
+                frames_per_batch: int = 128) -> Tuple[np.ndarray, np.ndarray]:
+    """bases[F][nbase], delays / gains[F][M][K], totals[F] (main.py:102) -> (tables[F][P], lengths[F]).
+
+    ``trim_len`` = int(duration * fs) (main.py:119-120).  ``frames_per_batch`` bounds the HBM held by one batch
+    (waveforms of a batch: 3 buffers of frames x M x L doubles)."""
+    eng = engine or default_engine()
+    nf = len(bases)
+    if not (len(delays) == len(gains) == len(totals) == nf) or nf == 0:
+        raise ValueError("one base, path table and total length per frame")
+    m, k = np.asarray(delays[0]).shape
+    npairs = m * (m - 1) // 2
+    prm = make_params(fs, 1, "median", 1.0, max_expected_delay)
+    if filter_method in ("butterworth", "fir"):
+        design = _filter_design(fs, filter_method, 300, 3400, 101)
+    elif filter_method == "wiener":
+        design = None
+    else:
+        raise ValueError("Unknown filter method. Available methods: 'butterworth', 'fir', 'wiener'")
+    tables = np.zeros((nf, npairs), dtype=RECORD)
+    lengths = np.zeros(nf, dtype=np.int64)
+
+    by_total: Dict[Tuple[int, int], List[int]] = defaultdict(list)          # frames that share the simulation transform
+    for f in range(nf):
+        by_total[(int(totals[f]), len(bases[f]))].append(f)
+    for (total, nbase), members in by_total.items():
+        out_len = trim_len if 0 < trim_len < total else total
+        for at in range(0, len(members), frames_per_batch):
+            group = members[at: at + frames_per_batch]
+            b = len(group)
+            base = np.ascontiguousarray([bases[f] for f in group], dtype=np.float64)
+            dl = np.ascontiguousarray([delays[f] for f in group], dtype=np.float64)
+            gn = np.ascontiguousarray([gains[f] for f in group], dtype=np.float64)
+            d_base, d_dl, d_gn = eng.alloc(base.nbytes), eng.alloc(dl.nbytes), eng.alloc(gn.nbytes)
+            d_sim = eng.alloc(b * m * out_len * 8)
+            try:
+                eng.upload(d_base, base); eng.upload(d_dl, dl); eng.upload(d_gn, gn)
+                eng.simulate_multipath_dev(d_base, b, nbase, fs, total, d_dl, d_gn, m, k, trim_len, d_sim)      # main.py:165
+                ref, kpk, win, pk, refpk = eng.sync_measure_dev(d_sim, b, m, out_len)                          # utils.py:413-427
+                pads = np.zeros((b, m), dtype=np.int32)
+                for q in range(b):                                                                            # utils.py:428-451
+                    shifts = sync_shifts_from_measurements(kpk[q], win[q], pk[q], refpk[q], int(ref[q]), [out_len] * m, out_len, fs)
+                    lowest = min(shifts)
+                    pads[q] = [max(0, int(round(sh - lowest))) for sh in shifts]
+                by_len: Dict[int, List[int]] = defaultdict(list)
+                for q in range(b):
+                    by_len[out_len + int(pads[q].max())].append(q)
+                for length, local in by_len.items():                 # frames of one synchronised length: one pair-table call
+                    nb = len(local)
+                    d_al, d_flt, d_tab = eng.alloc(nb * m * length * 8), eng.alloc(nb * m * length * 8), eng.alloc(nb * npairs * RECORD.itemsize)
+                    try:
+                        contiguous = local == list(range(local[0], local[0] + nb))
+                        if contiguous:
+                            eng.align_rows_dev(d_sim + local[0] * m * out_len * 8, nb * m, out_len, pads[local].reshape(-1), length, d_al)
+                        else:
+                            for i, q in enumerate(local):
+                                eng.align_rows_dev(d_sim + q * m * out_len * 8, m, out_len, pads[q], length, d_al + i * m * length * 8)
+                        if design is None:
+                            eng.wiener3_dev(d_al, nb * m, length, d_flt)                                       # main.py:191
+                        else:
+                            eng.filtfilt_dev(design[0], design[1], design[2], d_al, nb * m, length, d_flt)
+                        eng.gcc_phat_all_pairs_dev(d_flt, nb, m, length, prm, d_tab)                           # main.py:202-228
+                        eng.synchronize()
+                        got = np.zeros((nb, npairs), dtype=RECORD)
+                        eng.download(got, d_tab)
+                        for i, q in enumerate(local):
+                            tables[group[q]] = got[i]
+                            lengths[group[q]] = length
+                    finally:
+                        eng.free(d_al); eng.free(d_flt); eng.free(d_tab)
+            finally:
+                eng.free(d_base); eng.free(d_dl); eng.free(d_gn); eng.free(d_sim)
+    return tables, lengths

@@ -7,7 +7,7 @@ import numpy as np
 
 
 def metric_frames(batch: int, mics: int = 64, n: int = 44100, first: int = 0) -> np.ndarray:
-    delays = np.random.default_rng(8).integers(-60, 60, size=64)[:mics]
+    delays = np.random.default_rng(8).integers(-60, 60, size=max(64, mics))[:mics]   # (the first 64 do not depend on the count)
     out = np.empty((batch, mics, n))
     for b in range(batch):
         g = np.random.default_rng([7, first + b])

@@ -261,32 +261,15 @@ def compute_weights(correlation_metrics, mic_pairs) -> np.ndarray:
 
 
 # ---------------------------------------------------------------- synchronisation (GPU correlations)
-def synchronize_signals_improved(signals: List[np.ndarray], fs: float, use_interpolation: bool = True) -> List[np.ndarray]:
-    """Align every signal to the highest-energy one (utils.py:407-457).  The M full cross-correlations
-    and their argmax run on the engine; the 5-point spline refinement and zero padding are host work.
-
-    Signals of different lengths are accepted like in the reference (recordings read by read_audio_files seldom
-    agree to the sample): for the engine call only, every row is zero-padded at its end to the longest length
-    Lmax.  Trailing zeros leave correlate(sig, ref, 'full') unchanged lag by lag - index k of the reference's
-    sequence (length len(sig) + len(ref) - 1) sits at k + (Lmax - len(ref)) of the padded one - so the shift is
-    k' - (Lmax - 1), and the pads are applied to the ORIGINAL rows as utils.py:448-456 does."""
+def sync_shifts_from_measurements(kpk, win, pkabs, ref_peak, ref_idx, lens, lmax, fs, use_interpolation=True) -> List[float]:
+    """Host half of utils.py:420-446: the engine's per-row measurements (argmax |corr| index into the padded
+    2 lmax - 1 sequence, the five samples around it, |peak|, the reference's autocorrelation peak) -> float shifts,
+    with the reference's quirks kept (low peak: shift NOT zeroed; |shift| > 50 ms: zeroed)."""
     from scipy.interpolate import CubicSpline
-    sigs = [np.asarray(s, dtype=np.float64) for s in signals]
-    lens = [len(s) for s in sigs]
-    lmax = max(lens)
-    if len(set(lens)) == 1:
-        rows = np.asarray(sigs, dtype=np.float64)
-    else:
-        rows = np.zeros((len(sigs), lmax))
-        for r, s in zip(rows, sigs):
-            r[: len(s)] = s
-    energies = [np.sum(s ** 2) for s in sigs]
-    ref_idx = int(np.argmax(energies))
     nref = lens[ref_idx]
-    kpk, win, pkabs, ref_peak = default_engine().xcorr_vs_ref(rows, ref_idx)
     limit = int(fs * 0.05)
     shifts: List[float] = []
-    for idx in range(rows.shape[0]):
+    for idx in range(len(lens)):
         if idx == ref_idx:
             shifts.append(0)
             continue
@@ -302,6 +285,31 @@ def synchronize_signals_improved(signals: List[np.ndarray], fs: float, use_inter
             log.warning("shift of %s samples for signal %d is implausible, using 0", shift, idx)
             shift = 0
         shifts.append(shift)
+    return shifts
+
+
+def synchronize_signals_improved(signals: List[np.ndarray], fs: float, use_interpolation: bool = True) -> List[np.ndarray]:
+    """Align every signal to the highest-energy one (utils.py:407-457).  The M full cross-correlations
+    and their argmax run on the engine; the 5-point spline refinement and zero padding are host work.
+
+    Signals of different lengths are accepted like in the reference (recordings read by read_audio_files seldom
+    agree to the sample): for the engine call only, every row is zero-padded at its end to the longest length
+    Lmax.  Trailing zeros leave correlate(sig, ref, 'full') unchanged lag by lag - index k of the reference's
+    sequence (length len(sig) + len(ref) - 1) sits at k + (Lmax - len(ref)) of the padded one - so the shift is
+    k' - (Lmax - 1), and the pads are applied to the ORIGINAL rows as utils.py:448-456 does."""
+    sigs = [np.asarray(s, dtype=np.float64) for s in signals]
+    lens = [len(s) for s in sigs]
+    lmax = max(lens)
+    if len(set(lens)) == 1:
+        rows = np.asarray(sigs, dtype=np.float64)
+    else:
+        rows = np.zeros((len(sigs), lmax))
+        for r, s in zip(rows, sigs):
+            r[: len(s)] = s
+    energies = [np.sum(s ** 2) for s in sigs]
+    ref_idx = int(np.argmax(energies))
+    kpk, win, pkabs, ref_peak = default_engine().xcorr_vs_ref(rows, ref_idx)
+    shifts = sync_shifts_from_measurements(kpk, win, pkabs, ref_peak, ref_idx, lens, lmax, fs, use_interpolation)
     lowest = min(shifts)
     padded = [np.pad(s, (max(0, int(round(sh - lowest))), 0)) for s, sh in zip(sigs, shifts)]
     length = max(len(p) for p in padded)

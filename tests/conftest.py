@@ -18,6 +18,19 @@ def pytest_configure(config):
         subprocess.run(["make", "-C", os.path.join(ROOT, "pyaudiolocalization_amd", "csrc"), "-j", "4"], check=True)
 
 
+def pytest_sessionstart(session):
+    """Start multiprocessing's fork server NOW, before any test touches the GPU.  The two-rank GPU test
+    (tests/test_gpu_stream.py) starts its rank processes through it: they are forks of this clean server, so no process
+    that has initialised HIP ever forks or execs (the GPU boxes forbid an exec from such a process)."""
+    import multiprocessing
+    import multiprocessing.forkserver as forkserver
+    try:
+        multiprocessing.get_context("forkserver")
+        forkserver.ensure_running()
+    except Exception as exc:                     # reported, never fatal: only the two-rank GPU test needs it
+        print(f"[conftest] fork server not started: {exc}")
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
