@@ -18,7 +18,6 @@ namespace pal {
 // One circular convolution of length M = M1 x M2 (four-step, both factors in LDS).
 // M2 = 2^l2; M1 = 2^l1, or 3 * 2^l1 (r3) when the 3 * 2^k length is the smaller fit.
 struct PeakArgs;    // peak_types.h
-struct PfaSample;   // pfa_sample.h
 
 struct Conv {
   int l1 = 0, l2 = 0;
@@ -159,11 +158,10 @@ struct Engine {
   int peaks(const double* corr, size_t stride, int rows, int n, int n2, const pal_phat_params& prm,
             pal_pair_record* table, int32_t* ksel_multi, hipStream_t on);
   // the same in pieces, for the column pass that produces the streaming statistics itself (pfa_cols_stats.h):
-  // arguments + scratch (segments = `blocks` column blocks of a grid with rows of grid_n2), pivots from the grid,
+  // arguments + scratch (segments = `blocks` column blocks of a grid with rows of grid_n2, each with its own pivots),
   // [the caller's fused column launch], the finish launch
   int peaks_setup(const double* corr, size_t stride, int rows, int n, int n2, const pal_phat_params& prm, int blocks, int grid_n2,
                   hipStream_t on, PeakArgs& a);
-  int peaks_pivots_grid(const PeakArgs& a, int rows, const PfaSample& sp, hipStream_t on);
   int peaks_finish(PeakArgs& a, int rows, pal_pair_record* table, int32_t* ksel_multi, hipStream_t on);
   int pfa_rows(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, hipStream_t on);
   bool pfa_can_fuse(const Plan& pl) const;
@@ -173,8 +171,8 @@ struct Engine {
   bool pfa_forward_applies(const Plan& pl, int len) const;
   int pfa_forward_spectra(Plan& pl, const double* frames, size_t frame_stride, int rows, int len, cd* spectra);
   bool pfa_forward = true;    // PAL_PFA_FWD=0: forward spectra on the four-step route even where the prime-factor cut applies
-  bool fuse_peaks = false;    // PAL_FUSED=1: column pass + peak statistics in one launch where it applies (pfa_cols_stats.h;
-                              // measured break-even at 44.1 kHz x 1 s: the pivots then cost a pass over the grid)
+  bool fuse_peaks = true;     // PAL_FUSED=0: separate column pass + pivot / stream launches instead of the fused column pass +
+                              // peak statistics (pfa_cols_stats.h) where that applies
 };
 
 struct ProfScope {

@@ -18,6 +18,9 @@ struct RowPre {                          // pivot launch -> the other two
 struct Partial {                         // one segment's share of the streaming pass
   double vmax, vmin, hb, s1, s2, a1, a2;
   double plat;                           // fused column pass only: highest sample with an equal neighbour (-inf: none)
+  double lo, hi;                         // fused column pass only: the pivots THIS segment used (its own block sample); `below`
+                                         // counts its values under lo, its share of the row's list holds those in [lo, hi]
+  double pfloor;                         // fused column pass only: samples of this segment below it had no peak test
   long long below;
   int imax, imin, mb, pad;
 };
@@ -29,6 +32,7 @@ struct PeakArgs {
   double fs, mult, med;   // med: NaN = no window
   int method, dist, num_peaks, snr_w;   // method: 0 median, 1 adaptive, < 0 metrics only
   int splits, tiles_per_seg;             // segments per row, tiles per segment
+  int local_pivots;                      // 1: every segment brought its own pivots (Partial.lo / hi / pfloor), no RowPre
   int edge_n2;                           // > 0: segments are column blocks of the prime-factor grid (row length edge_n2);
                                          //      the finish launch tests the samples of columns 0 and edge_n2 - 1 itself
   RowPre* pre;                           // [rows]

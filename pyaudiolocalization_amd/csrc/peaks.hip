@@ -205,8 +205,10 @@ __device__ __forceinline__ bool peak_mid(const double* c, int n, int m, double& 
 // ---- exact rank inside the row's bracket list (global memory, L2-resident) whose values lie in [lo, hi] ----
 // linear bins spread the bracket over the histogram; the winning bin (a handful of values) is ranked by counting.
 // returns false when that bin is too crowded for the exact search (caller falls back to the radix select)
+// `flo` / `fhi`: only list values inside [flo, fhi] take part (the fused column pass lists per-segment brackets; the
+// median is searched in their intersection); `rank` counts inside that filtered set.
 __device__ bool list_select(Shared& s, int tid, const double* __restrict__ list, int cnt, unsigned rank, double lo, double hi,
-                            double& out) {
+                            double& out, double flo = -INFINITY, double fhi = INFINITY) {
   constexpr int kKeep = 16;                                    // list values a lane keeps in registers between the two passes
   for (int k = tid; k < kBins; k += kT) s.hist[k] = 0;
   if (tid == 0) s.count2 = 0;
@@ -223,10 +225,14 @@ __device__ bool list_select(Shared& s, int tid, const double* __restrict__ list,
     const int e = tid + q * kT;
     keep[q] = e < cnt ? list[e] : 0.0;
   }
+  auto pass = [&](double v) { return v >= flo && v <= fhi; };
 #pragma unroll
   for (int q = 0; q < kKeep; ++q)
-    if (tid + q * kT < cnt) atomicAdd(&s.hist[bin_of(keep[q])], 1u);
-  for (int e = tid + kKeep * kT; e < cnt; e += kT) atomicAdd(&s.hist[bin_of(list[e])], 1u);
+    if (tid + q * kT < cnt && pass(keep[q])) atomicAdd(&s.hist[bin_of(keep[q])], 1u);
+  for (int e = tid + kKeep * kT; e < cnt; e += kT) {
+    const double v = list[e];
+    if (pass(v)) atomicAdd(&s.hist[bin_of(v)], 1u);
+  }
   __syncthreads();
   unsigned bin, inner, pop;
   find_bin(s, tid, rank, bin, inner, pop);
@@ -234,13 +240,13 @@ __device__ bool list_select(Shared& s, int tid, const double* __restrict__ list,
   // the winning bin holds a handful of values: a lane that owns one takes a slot with its own LDS atomic
 #pragma unroll
   for (int q = 0; q < kKeep; ++q)
-    if (tid + q * kT < cnt && unsigned(bin_of(keep[q])) == bin) {
+    if (tid + q * kT < cnt && pass(keep[q]) && unsigned(bin_of(keep[q])) == bin) {
       const int at = atomicAdd(&s.count2, 1);
       if (at < kSmall) s.small[at] = keep[q];
     }
   for (int e = tid + kKeep * kT; e < cnt; e += kT) {
     const double v = list[e];
-    if (unsigned(bin_of(v)) == bin) {
+    if (pass(v) && unsigned(bin_of(v)) == bin) {
       const int at = atomicAdd(&s.count2, 1);
       if (at < kSmall) s.small[at] = v;
     }
@@ -606,43 +612,6 @@ __global__ __launch_bounds__(kT) void k_peak_pivots(PeakArgs a) {
   pivot_search<kRuns>(a, s, tid, row, sv, real, ns, vm, pm);
 }
 
-// the same for a row that does not exist yet: sample values computed from the prime-factor grid (pfa_sample.h)
-template <int TC> __global__ __launch_bounds__(kT) void k_peak_pivots_grid(PeakArgs a, PfaSample sp) {
-  __shared__ Shared s;
-  const int tid = threadIdx.x;
-  const int row = blockIdx.x;
-  __shared__ double tab[kSampleTabMax];
-  double sv[2 * TC];
-  pfa_sample_row<TC>(sp, row, tid, tab, sv);
-  bool real[2 * TC];
-  const int ch = tid >> 7, h = (sp.N1 - 1) / 2;
-  int per_col = 0;                                            // values per sampled column over the four chunks (uniform)
-  for (int c4 = 0; c4 < 4; ++c4)
-    for (int tt = 0; tt < TC; ++tt) per_col += (c4 < sp.nch && c4 * TC + tt + 1 <= h) ? 2 : 0;
-#pragma unroll
-  for (int tt = 0; tt < TC; ++tt) real[tt] = real[TC + tt] = ch < sp.nch && ch * TC + tt + 1 <= h;
-  // Lower bounds for the column pass: the sample's maximum, and its highest strict peak (the clusters of 8 neighbouring
-  // columns give the six inner lanes of a cluster both neighbours m -/+ 1 of the same output index).  The values are the
-  // row's own (same operations in the same order as the column pass); a relative 1e-9 of slack anyway, and the finish
-  // launch rescans a row whose best peak ends up below the bound.
-  const int within = tid & 7;
-  double vm = -INFINITY, pm = -INFINITY;
-#pragma unroll
-  for (int q = 0; q < 2 * TC; ++q) {
-    const double x = sv[q];
-    const double left = from_lower_lane(x), right = from_upper_lane(x);
-    vm = real[q] ? fmax(vm, x) : vm;
-    pm = real[q] && within >= 1 && within <= 6 && left < x && right < x ? fmax(pm, x) : pm;
-  }
-  vm = block_max<kNW>(vm, s.red_d, tid);
-  __syncthreads();
-  pm = block_max<kNW>(pm, s.red_d, tid);
-  __syncthreads();
-  vm -= fabs(vm) * 1e-9;
-  pm -= fabs(pm) * 1e-9;
-  pivot_search<2 * TC>(a, s, tid, row, sv, real, per_col * kSampleCols, vm, pm);
-}
-
 // ------------------------------------------------------------------ 2. stream
 __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
   __shared__ StreamShared s;
@@ -857,6 +826,7 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
     pt.vmax = vmax; pt.vmin = vmin; pt.hb = hb; pt.s1 = sums[0]; pt.s2 = sums[1]; pt.a1 = sums[2]; pt.a2 = sums[3];
     pt.below = (long long)sums[4]; pt.imax = imax; pt.imin = imin; pt.mb = mb; pt.pad = 0;
     pt.plat = -INFINITY;
+    pt.lo = 0; pt.hi = INFINITY; pt.pfloor = -INFINITY;        // (the row's pivots come from the pivot launch on this path)
     a.parts[size_t(row) * S + seg] = pt;
   }
 }
@@ -870,8 +840,12 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   const double* c = a.corr + size_t(row) * a.stride;
   const int n = a.n;
   const bool want_median = a.method == 0;
-  const RowPre pre = load_pre(a.pre, row);
-  const double k0 = pre.k0, ka = pre.ka, lo = pre.lo, hi = pre.hi;
+  const bool local = a.local_pivots != 0;                     // fused column pass: zero shifts, per-segment pivots (Partial)
+  RowPre pre;
+  if (local) { pre.k0 = pre.ka = 0; pre.lo = 0; pre.hi = INFINITY; pre.vfloor = pre.pfloor = -INFINITY; }
+  else pre = load_pre(a.pre, row);
+  const double k0 = pre.k0, ka = pre.ka;
+  double lo = pre.lo, hi = pre.hi;
   const unsigned r1 = unsigned((n - 1) / 2), r2 = unsigned(n / 2);   // ranks of the median's one or two order statistics
   int stamp_at = 0;
   auto stamp = [&]() {
@@ -893,6 +867,11 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
     if (pt.mb >= 0 && (mb < 0 || higher(pt.hb, pt.mb, hb, mb))) { hb = pt.hb; mb = pt.mb; }
     s1 += pt.s1; s2 += pt.s2; a1 += pt.a1; a2 += pt.a2;
     below += pt.below;
+    if (local) {                                               // intersection of the segments' brackets; highest untested bound
+      lo = fmax(lo, pt.lo);
+      hi = fmin(hi, pt.hi);
+      pre.pfloor = fmax(pre.pfloor, pt.pfloor);
+    }
   }
   stamp();
   const int cnt = want_median ? a.gcount[row] : 0;
@@ -999,9 +978,34 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   double thr1;
   if (want_median) {
     double m0 = 0, m1 = 0;
-    bool ok = cnt >= 0 && cnt <= kList && (long long)r1 >= below && (long long)r2 < below + cnt;
-    if (ok) ok = list_select(s, tid, list, cnt, unsigned(r1 - below), lo, hi, m0);
-    if (ok) { m1 = m0; if (r2 != r1) ok = list_select(s, tid, list, cnt, unsigned(r2 - below), lo, hi, m1); }
+    bool ok;
+    if (local) {
+      // Every segment listed its values inside its OWN bracket [lo_s, hi_s] and counted those below lo_s.  Inside the
+      // intersection [lo, hi] = [max lo_s, min hi_s] the union of the lists is complete; below it are the segments'
+      // counts plus the listed values under lo.
+      ok = cnt >= 0 && cnt <= kList && lo <= hi;
+      long long under = 0, inside = 0;
+      if (ok) {
+        long long u = 0, in = 0;
+        for (int e = tid; e < cnt; e += kT) {
+          const double v = list[e];
+          u += v < lo;
+          in += v >= lo && v <= hi;
+        }
+        under = bsum_ll(u, s, tid);
+        __syncthreads();
+        inside = bsum_ll(in, s, tid);
+        __syncthreads();
+        const long long base = below + under;
+        ok = (long long)r1 >= base && (long long)r2 < base + inside;
+        if (ok) ok = list_select(s, tid, list, cnt, unsigned(r1 - base), lo, hi, m0, lo, hi);
+        if (ok) { m1 = m0; if (r2 != r1) ok = list_select(s, tid, list, cnt, unsigned(r2 - base), lo, hi, m1, lo, hi); }
+      }
+    } else {
+      ok = cnt >= 0 && cnt <= kList && (long long)r1 >= below && (long long)r2 < below + cnt;
+      if (ok) ok = list_select(s, tid, list, cnt, unsigned(r1 - below), lo, hi, m0);
+      if (ok) { m1 = m0; if (r2 != r1) ok = list_select(s, tid, list, cnt, unsigned(r2 - below), lo, hi, m1); }
+    }
     if (!ok && tid == 0) atomicAdd(status + 1, 1);             // diagnostics: rows that needed the slow exact select
     if (!ok) {                                                 // pivots missed or a list overflowed: exact radix select
       m0 = radix_select(c, n, tid, s, r1);
@@ -1092,6 +1096,7 @@ int Engine::peaks_setup(const double* corr, size_t stride, int rows, int n, int 
   const int w = int(0.01 * double(n));                       // utils.py:244
   a.snr_w = w > 1 ? w : 1;
   a.edge_n2 = blocks > 0 ? grid_n2 : 0;
+  a.local_pivots = blocks > 0 ? 1 : 0;
   a.stamps = nullptr;
   if (blocks > 0) {
     a.splits = blocks;
@@ -1119,12 +1124,6 @@ int Engine::peaks_setup(const double* corr, size_t stride, int rows, int n, int 
   a.parts = reinterpret_cast<Partial*>(base + off_parts);
   a.glist = reinterpret_cast<double*>(base + off_list);
   return PAL_OK;
-}
-
-int Engine::peaks_pivots_grid(const PeakArgs& a, int rows, const PfaSample& sp, hipStream_t on) {
-  ProfScope ps(this, "k_peak_pivots_grid", on);
-  k_peak_pivots_grid<kPfaTC><<<dim3(rows), dim3(kT), 0, on>>>(a, sp);
-  return check(hipGetLastError(), "k_peak_pivots_grid");
 }
 
 int Engine::peaks_finish(PeakArgs& a, int rows, pal_pair_record* table, int32_t* ksel_multi, hipStream_t on) {

@@ -279,15 +279,14 @@ int Engine::pfa_forward_spectra(Plan& pl, const double* frames, size_t frame_str
   return PAL_OK;
 }
 
-// the fused column pass applies when one workgroup covers every output index (nch <= 4) and the grid is large
-// enough for the block sample of the pivots (pfa_sample.h: 128 columns x 64 or more output indices)
+// the fused column pass applies when one workgroup covers every output index (nch <= 4 chunks of kPfaTC: N1 <= 89)
 bool Engine::pfa_can_fuse(const Plan& pl) const {
   const Pfa& f = pl.pfa;
-  return fuse_peaks && f.on() && f.nch >= 3 && f.nch <= 4 && f.n1 <= 89 && f.n2 >= 128;
+  return fuse_peaks && f.on() && f.nch >= 1 && f.nch <= 4 && f.n2 >= 3;
 }
 
-// row pass, pivots from the grid, column pass + streaming statistics, finish: the peak selection of one launch
-// group without the separate read of its correlation rows (pfa_cols_stats.h)
+// row pass, column pass + streaming statistics (every column block with its own pivots), finish: the peak selection of
+// one launch group without a pivot launch and without the separate read of its correlation rows (pfa_cols_stats.h)
 int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, double* corr, size_t stride,
                                  const int* zero_rows, const pal_phat_params& prm, int n2, pal_pair_record* table, int32_t* ksel_multi,
                                  hipStream_t on) {
@@ -295,9 +294,8 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
   const int nblk = (f.n2 + kColsOwn - 1) / kColsOwn;
   PeakArgs a;
   PAL_TRY(peaks_setup(corr, stride, rows, pl.n, n2, prm, nblk, f.n2, on, a));
+  PAL_HIP(hipMemsetAsync(a.gcount, 0, size_t(rows) * sizeof(int), on));     // the rows' bracket lists start empty
   PAL_TRY(pfa_rows(pl, permuted, quads, G, Y, on));
-  const PfaSample sp{Y, f.T, zero_rows, f.n1, f.n2, f.nch};
-  PAL_TRY(peaks_pivots_grid(a, rows, sp, on));
   {
     ProfScope ps(this, "k_pfa_cols_stats", on);
     k_pfa_cols_stats<kPfaTC, kPfaUnr><<<dim3(unsigned(G) * unsigned(nblk)), dim3(256), 0, on>>>(Y, corr, stride, f.n1, f.n2, G, f.nch, f.T, zero_rows, a, rows);

@@ -1,25 +1,33 @@
 // pfa_cols_stats.h - column pass of the prime-factor route that also does the streaming pass of the peak
-// selection (gfx950, fp64).
+// selection (gfx950, fp64): no pivot launch, no second read of the correlation rows.
 //
 // k_pfa_cols (pfa_kernels.h) writes the correlation rows and k_peak_stream (peaks.hip) reads them back once for
-// the statistics the finish launch needs: max / argmax, min, the shifted sums, the highest local maximum, the
-// count below the lower pivot and the values between the pivots.  Here the values meet those statistics in the
-// registers they were accumulated in, and the 0.7 MB per row are only written (the finish launch still reads the
-// few hundred samples around the peaks it resolves).
+// the statistics the finish launch needs: max / argmax, min, the sums behind SNR and thresholds, the highest local
+// maximum, the count below the lower pivot and the values between the pivots that bracket the median of |corr|
+// (utils.py:145).  Here the values meet those statistics in the registers they were accumulated in, and the 0.7 MB per
+// row are only written (the finish launch still reads the few thousand samples around the peaks it resolves).
 //
 //   - a workgroup owns 62 columns m2 of one packed transform (both rows: pair p = real parts, pair q = imaginary
 //     parts) and all N1 output indices t, its four wavefronts four chunks of kPfaTC indices and their mirrors;
 //     lanes 0 and 63 compute the neighbouring blocks' border columns again, so that every owned sample has both
 //     neighbours m -/+ 1 = (m2 -/+ 1, t) one lane away (DPP wave shifts)
+//   - the pivots are the workgroup's OWN: pass A puts |x| of its ~5500 samples per row into a logarithmic histogram in
+//     LDS (32 bins per octave over 64 octaves below 1.0 - a PHAT sequence never exceeds 1) and takes the exact maximum;
+//     the bins that hold the local ranks cnt/2 -/+ (3 sqrt(cnt) + 8) give the bracket [lo, hi] of THIS block (6 sigma of
+//     a sample median's rank: about 9 % of the samples fall inside).  The finish launch intersects the blocks' brackets:
+//     inside [max lo, min hi] the union of the blocks' lists holds every sample of the row, the counts below it are the
+//     blocks' `below` plus the listed values under max lo, and the median is found by rank there (exact; a miss falls
+//     back to the radix select over the row).  No sample of the row is needed before this launch: the former pivot
+//     launch (a latency-bound pass over 12 % of Y) is gone.
+//   - pass B (same registers): stores, min, sums, count below / list between the pivots; the index bookkeeping of the
+//     maximum and of the highest strict peak sits behind a wave-uniform test against the block's exact maximum and
+//     0.8 of it (a sample below them can be neither the block's maximum nor, unless none of the samples above is a
+//     strict peak, its highest peak - the finish launch rescans a row whose best peak ends up below a block's bound)
 //   - the first and last column of the grid have their neighbours in another output index: their peak test is left
 //     to the finish launch (2 N1 samples per row), like the samples with an equal neighbour (plateaus), which are
 //     only reported
 //   - a lane meets its samples in increasing lag order (t = 0, the chunk ascending, the mirrors descending), so the
 //     first maximum / last peak of equal height win without index comparisons, as in the stream kernel
-//   - bracket values: a private LDS list per wavefront and row (ballot + mbcnt, no atomics), one global atomic per
-//     workgroup and row
-//   - the pivots come from k_peak_pivots_grid (a block sample computed from the grid, pfa_sample.h) in front of
-//     this launch
 #pragma once
 #include <cmath>
 
@@ -29,23 +37,41 @@
 namespace pal {
 
 constexpr int kColsOwn = 62;      // columns a workgroup of the fused column pass owns (64 lanes - two border lanes)
-constexpr int kColsList = 256;    // bracket values per wavefront and row (about 95 expected at 6 sigma pivots)
+constexpr int kColsList = 320;    // bracket values per wavefront and row (about 135 expected at 6 sigma of the block's rank)
+constexpr int kLogBins = 2048;    // 32 bins per octave x 64 octaves below 1.0
 
 struct ColsWaveResult {           // one wavefront's share of a row segment
-  double vmax, vmin, hb, s1, s2, a1, a2, plat;
+  double vmax, vmin, hb, s1, s2, a1, plat;
   int imax, mb, below, pad;
 };
 
 __device__ __forceinline__ double shfl_down_d(double v, int o) { return __shfl_down(v, o, 64); }
 
+// logarithmic bin of |x|: exponent and five mantissa bits, bin 2047 = [1, 1.03..) (and everything above), bin 0 =
+// everything below 2^-63 (zero included)
+__device__ __forceinline__ int log_bin(double mag) {
+  const int key = (__double2hiint(mag) & 0x7fffffff) >> 15;            // 11 exponent bits + 5 mantissa bits
+  const int b = key - (1023 * 32 - (kLogBins - 1));
+  return b < 0 ? 0 : (b > kLogBins - 1 ? kLogBins - 1 : b);
+}
+__device__ __forceinline__ double log_bin_floor(int b) {                // smallest magnitude of bin b (0 for bin 0)
+  if (b <= 0) return 0.0;
+  if (b > kLogBins - 1) return INFINITY;
+  return __hiloint2double((b + (1023 * 32 - (kLogBins - 1))) << 15, 0);
+}
+
 template <int TC, int UNR>
 __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride, int N1, int N2,
                                                         int G, int nch, const double* __restrict__ T, const int* __restrict__ zero_rows, PeakArgs pa,
                                                         int rows) {
+  __shared__ unsigned hist[2][kLogBins];
   __shared__ double list[4][2][kColsList + 1];                // + one dump slot for the unconditional stores
   __shared__ ColsWaveResult res[4][2];
   __shared__ int lcount[4][2];
   __shared__ int gbase[2];
+  __shared__ double wmax[4][2];
+  __shared__ unsigned wtot[4][2];
+  __shared__ int bins[2][2];                                  // [row][lower / upper]: histogram bins of the bracket
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = wave;                                        // nch <= 4: one workgroup covers every output index
@@ -58,6 +84,11 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
   const int m2c = m2 < 0 ? 0 : (m2 < N2 ? m2 : N2 - 1);       // border lanes outside the grid repeat its first / last column
   const cd* Yg = Y + size_t(g) * N1 * N2 + m2c;
   const int h = (N1 - 1) / 2;
+  {                                                           // histograms of both rows start empty (the loads below are in flight meanwhile)
+    uint4* hz = reinterpret_cast<uint4*>(&hist[0][0]);
+#pragma unroll
+    for (int q = 0; q < 2 * kLogBins / 4 / 256; ++q) hz[tid + 256 * q] = make_uint4(0, 0, 0, 0);
+  }
   double cx[TC], sy[TC], cy[TC], sx[TC];
   double sumx = 0, sumy = 0;
   cd y0 = mk(0, 0);
@@ -72,69 +103,125 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
       cx[tt] *= kp; sy[tt] *= kp; cy[tt] *= kq; sx[tt] *= kq;
     }
   }
+  // the samples of this lane in lag order: t = 0 (chunk 0 only), the chunk ascending, the mirrors descending
+  auto each_sample = [&](int r, auto&& fn) {                   // fn(x, t, exists); `exists` is wave-uniform
+    const double base = r ? y0.y : y0.x;
+    fn(base + (r ? sumy : sumx), 0, ch == 0);
+#pragma unroll
+    for (int tt = 0; tt < TC; ++tt) {
+      const int t = ch * TC + tt + 1;
+      fn(r ? base + cy[tt] + sx[tt] : base + cx[tt] - sy[tt], t, t <= h);
+    }
+#pragma unroll
+    for (int tt = TC - 1; tt >= 0; --tt) {
+      const int t = ch * TC + tt + 1;
+      fn(r ? base + cy[tt] - sx[tt] : base + cx[tt] + sy[tt], N1 - t, t <= h);
+    }
+  };
+  __syncthreads();                                             // the zeroed histograms are visible
+
+  // ---- pass A: the block's histogram of |x| and exact maximum, per row
+  const int nrow = 2 * g + 1 < rows ? 2 : 1;                   // odd tail: the last transform carries one pair (uniform)
+  if (active) {
+    for (int r = 0; r < nrow; ++r) {
+      double vm = -INFINITY;
+      each_sample(r, [&](double x, int, bool exists) {
+        if (!exists) return;
+        vm = own ? fmax(vm, x) : vm;
+        if (want_median && own) atomicAdd(&hist[r][log_bin(fabs(x))], 1u);
+      });
+      for (int o = 32; o > 0; o >>= 1) vm = fmax(vm, shfl_down_d(vm, o));
+      if (lane == 0) wmax[wave][r] = vm;
+    }
+  } else if (lane == 0) {
+    wmax[wave][0] = wmax[wave][1] = -INFINITY;
+  }
+  __syncthreads();
+  // ---- the bracket of this block: bins of the local ranks cnt/2 -/+ margin (every lane scans 8 bins of both rows)
+  if (want_median) {
+    constexpr int PER = kLogBins / 256;
+    unsigned hv[2][PER], sum[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < PER; ++q) { hv[r][q] = hist[r][PER * tid + q]; sum[r] += hv[r][q]; }
+    unsigned inc[2] = {sum[0], sum[1]};
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t0 = __shfl_up(inc[0], o, 64), t1 = __shfl_up(inc[1], o, 64);
+      if (lane >= o) { inc[0] += t0; inc[1] += t1; }
+    }
+    if (lane == 63) { wtot[wave][0] = inc[0]; wtot[wave][1] = inc[1]; }
+    if (tid < 4) bins[tid >> 1][tid & 1] = (tid & 1) ? kLogBins - 1 : 0;      // whole range unless a rank falls inside the counts
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned before = 0, cnt = 0;
+      for (int w = 0; w < 4; ++w) { before += w < wave ? wtot[w][r] : 0; cnt += wtot[w][r]; }
+      unsigned ex = before + inc[r] - sum[r];
+      const int margin = int(3.0f * sqrtf(float(cnt))) + 8;
+      const int mid = int(cnt >> 1);
+      const unsigned ra = unsigned(mid - margin > 0 ? mid - margin : 0);
+      const unsigned rb = unsigned(mid + margin < int(cnt) - 1 ? mid + margin : (cnt ? int(cnt) - 1 : 0));
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        if (hv[r][q] && ra >= ex && ra < ex + hv[r][q] && ra > 0) bins[r][0] = PER * tid + q;
+        if (hv[r][q] && rb >= ex && rb < ex + hv[r][q] && rb + 1 < cnt) bins[r][1] = PER * tid + q;
+        ex += hv[r][q];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- pass B: stores and statistics, with the block's own pivots and bounds
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int row = 2 * g + r;
-    if (row >= rows) { if (lane == 0) lcount[wave][r] = 0; continue; }     // odd tail: the last transform has one pair (uniform)
-    const RowPre pre = load_pre(pa.pre, row);
-    const double k0 = pre.k0, ka = pre.ka, lo = pre.lo, hi = pre.hi, vfloor = pre.vfloor, pfloor = pre.pfloor;
+    if (row >= rows) { if (lane == 0) lcount[wave][r] = 0; continue; }
+    const double lo = want_median ? log_bin_floor(bins[r][0]) : 0.0;
+    const double hi = want_median ? log_bin_floor(bins[r][1] + 1) : INFINITY;      // (inclusive upper pivot: the next bin's first value)
+    const double vfloor = fmax(fmax(wmax[0][r], wmax[1][r]), fmax(wmax[2][r], wmax[3][r]));   // the block's exact maximum
+    const double pfloor = vfloor > 0 ? 0.8 * vfloor : -INFINITY;
     double* const out = corr + size_t(row) * stride + m2c;
-    // Per-lane state.  A sample below the pivot launch's bounds (vfloor <= the row's maximum, pfloor <= its highest
-    // strict peak) can be neither, so the index bookkeeping and the neighbour exchange sit behind a wave-uniform branch
-    // that about one step in fifty takes.  A lane meets its samples in increasing lag order: the first maximum and the
-    // last peak of equal height win inside the lane, the merges compare indices.
+    // Per-lane state.  A lane meets its samples in increasing lag order: the first maximum and the last peak of equal
+    // height win inside the lane, the merges compare indices.
     double vmax = -INFINITY, vmin = INFINITY, hb = -INFINITY, plat = -INFINITY;
     int imax = -1, mb = -1;
-    double s1 = 0, s2 = 0, a1 = 0, a2 = 0;
+    double s1 = 0, s2 = 0, a1 = 0;
     int below = 0, run = 0;                                    // wave-uniform counts
     double* mylist = list[wave][r];
-    auto sample = [&](double x, int t, bool exists) {          // `exists` is wave-uniform
-      if (!exists) return;
-      out[N2 * t] = x;                                         // (border lanes store the value their column's owner stores)
-      vmin = fmin(vmin, x);                                    // (lanes that own nothing are reset below)
-      const double mag = fabs(x);
-      const double d = x - k0, e = mag - ka;
-      s1 += d;
-      s2 = __builtin_fma(d, d, s2);
-      a1 += e;
-      a2 = __builtin_fma(e, e, a2);
-      if (__ballot((own && x >= vfloor) || (inner && x >= pfloor))) {
-        const int m = m2 + N2 * t;
-        const bool up = own && x > vmax;
-        vmax = up ? x : vmax;
-        imax = up ? m : imax;
-        const double left = from_lower_lane(x), right = from_upper_lane(x);
-        const bool cand = inner && x >= pfloor && x >= hb;
-        const bool pk = cand && left < x && right < x;
-        hb = pk ? x : hb;
-        mb = pk ? m : mb;
-        // an equal pair (m - 1, m) is reported by its right element (here, or by the finish launch for the grid's edge columns)
-        plat = inner && x >= pfloor && left == x ? fmax(plat, x) : plat;
-      }
-      if (want_median) {
-        below += __popcll(__ballot(own && mag < lo));
-        const bool in = own && mag >= lo && mag <= hi;
-        const unsigned long long mask = __ballot(in);
-        const int at = run + int(__builtin_amdgcn_mbcnt_hi(unsigned(mask >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(mask), 0u)));
-        mylist[in ? min(at, kColsList) : kColsList] = mag;     // unconditional store, one dump slot
-        run += __popcll(mask);
-      }
-    };
     if (active) {
-      const double base = r ? y0.y : y0.x;
-      sample(base + (r ? sumy : sumx), 0, ch == 0);
-#pragma unroll
-      for (int tt = 0; tt < TC; ++tt) {
-        const int t = ch * TC + tt + 1;
-        sample(r ? base + cy[tt] + sx[tt] : base + cx[tt] - sy[tt], t, t <= h);
-      }
-#pragma unroll
-      for (int tt = TC - 1; tt >= 0; --tt) {
-        const int t = ch * TC + tt + 1;
-        sample(r ? base + cy[tt] - sx[tt] : base + cx[tt] + sy[tt], N1 - t, t <= h);
-      }
+      each_sample(r, [&](double x, int t, bool exists) {
+        if (!exists) return;
+        out[N2 * t] = x;                                       // (border lanes store the value their column's owner stores)
+        vmin = fmin(vmin, x);                                  // (lanes that own nothing are reset below)
+        const double mag = fabs(x);
+        s1 += x;
+        s2 = __builtin_fma(x, x, s2);
+        a1 += mag;
+        if (__ballot((own && x >= vfloor) || (inner && x >= pfloor))) {
+          const int m = m2 + N2 * t;
+          const bool up = own && x > vmax;
+          vmax = up ? x : vmax;
+          imax = up ? m : imax;
+          const double left = from_lower_lane(x), right = from_upper_lane(x);
+          const bool cand = inner && x >= pfloor && x >= hb;
+          const bool pk = cand && left < x && right < x;
+          hb = pk ? x : hb;
+          mb = pk ? m : mb;
+          // an equal pair (m - 1, m) is reported by its right element (here, or by the finish launch for the grid's edge columns)
+          plat = inner && x >= pfloor && left == x ? fmax(plat, x) : plat;
+        }
+        if (want_median) {
+          below += __popcll(__ballot(own && mag < lo));
+          const bool in = own && mag >= lo && mag <= hi;
+          const unsigned long long mask = __ballot(in);
+          const int at = run + int(__builtin_amdgcn_mbcnt_hi(unsigned(mask >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(mask), 0u)));
+          mylist[in ? min(at, kColsList) : kColsList] = mag;   // unconditional store, one dump slot
+          run += __popcll(mask);
+        }
+      });
     }
-    if (!own) { vmin = INFINITY; s1 = s2 = a1 = a2 = 0; }
+    if (!own) { vmin = INFINITY; s1 = s2 = a1 = 0; }
     // wavefront reduction (lane 0 holds the result)
     for (int o = 32; o > 0; o >>= 1) {
       const double ov = shfl_down_d(vmax, o);
@@ -147,12 +234,11 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
       s1 += shfl_down_d(s1, o);
       s2 += shfl_down_d(s2, o);
       a1 += shfl_down_d(a1, o);
-      a2 += shfl_down_d(a2, o);
       plat = fmax(plat, shfl_down_d(plat, o));
     }
     if (lane == 0) {
       ColsWaveResult w;
-      w.vmax = vmax; w.vmin = vmin; w.hb = hb; w.s1 = s1; w.s2 = s2; w.a1 = a1; w.a2 = a2; w.plat = plat;
+      w.vmax = vmax; w.vmin = vmin; w.hb = hb; w.s1 = s1; w.s2 = s2; w.a1 = a1; w.plat = plat;
       w.imax = imax; w.mb = mb; w.below = below; w.pad = 0;
       res[wave][r] = w;
       lcount[wave][r] = run;                                   // (> kColsList: the private list overflowed)
@@ -176,13 +262,18 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
       if (x.imax >= 0 && (pt.imax < 0 || x.vmax > pt.vmax || (x.vmax == pt.vmax && x.imax < pt.imax))) { pt.vmax = x.vmax; pt.imax = x.imax; }
       pt.vmin = fmin(pt.vmin, x.vmin);
       if (x.mb >= 0 && (pt.mb < 0 || higher(x.hb, x.mb, pt.hb, pt.mb))) { pt.hb = x.hb; pt.mb = x.mb; }
-      pt.s1 += x.s1; pt.s2 += x.s2; pt.a1 += x.a1; pt.a2 += x.a2;
+      pt.s1 += x.s1; pt.s2 += x.s2; pt.a1 += x.a1;
       pt.below += x.below;
       pt.plat = fmax(pt.plat, x.plat);
       overflow = overflow || lcount[w][r] > kColsList;
       total += lcount[w][r];
     }
+    pt.a2 = pt.s2;                                              // sum |x|^2 = sum x^2 (both shifts are zero on this path)
     pt.imin = 0;                                                // (the finish launch only asks whether the segment has a minimum)
+    pt.lo = want_median ? log_bin_floor(bins[r][0]) : 0.0;
+    pt.hi = want_median ? log_bin_floor(bins[r][1] + 1) : INFINITY;
+    const double bmax = fmax(fmax(wmax[0][r], wmax[1][r]), fmax(wmax[2][r], wmax[3][r]));
+    pt.pfloor = bmax > 0 ? 0.8 * bmax : -INFINITY;
     pa.parts[size_t(row) * pa.splits + cb] = pt;
     gbase[r] = want_median ? atomicAdd(&pa.gcount[row], overflow ? kList + 1 : total) : -1;   // an overflow poisons the list
   }

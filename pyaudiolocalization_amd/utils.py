@@ -170,6 +170,8 @@ def compute_cross_correlation_metrics(corr, sig1, sig2, fs, alpha: float = 0.05)
 
 
 # ---------------------------------------------------------------- TDOA -> position (host, 3 unknowns)
+SILHOUETTE_EXACT_MAX = 4096      # points up to which determine_optimal_number_of_clusters scores every pairwise distance
+
 def determine_optimal_number_of_clusters(data, max_clusters: int = 5, method: str = "kmeans", eps: float = 0.001,
                                          min_samples: int = 2) -> int:
     """Silhouette-best k for KMeans, or DBSCAN's cluster count when its silhouette is positive (utils.py:273-302)."""
@@ -180,8 +182,14 @@ def determine_optimal_number_of_clusters(data, max_clusters: int = 5, method: st
         return 1
     if method == "kmeans":
         best, best_k = -1, 1
+        # The silhouette needs all pairwise distances: O(P^2) time and memory (8.5 GB and minutes at the 32 640 pairs of a
+        # 256-microphone array).  Up to SILHOUETTE_EXACT_MAX points it is the reference's exact score; above, the score of a
+        # fixed random subset of that many points (sklearn's own sample_size option, seeded) - the choice of k it is used
+        # for is a property of the point cloud's shape, which the subset keeps.
+        sample = None if len(pts) <= SILHOUETTE_EXACT_MAX else SILHOUETTE_EXACT_MAX
         for k in range(2, min(max_clusters, len(pts)) + 1):
-            score = silhouette_score(pts, KMeans(n_clusters=k, random_state=0).fit(pts).labels_)
+            score = silhouette_score(pts, KMeans(n_clusters=k, random_state=0).fit(pts).labels_, sample_size=sample,
+                                     random_state=0)
             if score > best:
                 best, best_k = score, k
         return best_k
@@ -203,15 +211,26 @@ def heuristic_initialization_adaptive(mic_positions, mic_pairs, tdoas, c, cluste
     centroid = np.mean(mics, axis=0)
     if np.size(tdoas) == 0:
         return [centroid.tolist()]
-    points = []
-    for (i, j), td in zip(mic_pairs, np.array(tdoas)):
-        a, b = np.array(mic_positions[i]), np.array(mic_positions[j])
+    if len(mic_pairs) > SILHOUETTE_EXACT_MAX:          # same points, all pairs at once (the loop below costs seconds here)
+        pr = np.asarray(mic_pairs, dtype=np.int64).reshape(-1, 2)
+        td_all = np.asarray(tdoas, dtype=np.float64)[: pr.shape[0]]
+        a, b = mics[pr[:, 0]], mics[pr[:, 1]]
         axis = b - a
-        length = np.linalg.norm(axis)
-        if length == 0:
-            continue
-        shift = (c * abs(td)) / 2 * (axis / length)
-        points.append(((a + b) / 2 - shift if td > 0 else (a + b) / 2 + shift).tolist())
+        length = np.sqrt(np.sum(axis * axis, axis=1))
+        keep = length != 0
+        shift = ((c * np.abs(td_all[keep])) / 2)[:, None] * (axis[keep] / length[keep, None])
+        mid = (a[keep] + b[keep]) / 2
+        points = np.where((td_all[keep] > 0)[:, None], mid - shift, mid + shift).tolist()
+    else:
+        points = []
+        for (i, j), td in zip(mic_pairs, np.array(tdoas)):
+            a, b = np.array(mic_positions[i]), np.array(mic_positions[j])
+            axis = b - a
+            length = np.linalg.norm(axis)
+            if length == 0:
+                continue
+            shift = (c * abs(td)) / 2 * (axis / length)
+            points.append(((a + b) / 2 - shift if td > 0 else (a + b) / 2 + shift).tolist())
     if not points:
         return [centroid.tolist()]
     if clustering_method == "kmeans":
@@ -243,6 +262,11 @@ def dynamic_bounds_extended(mic_positions, tdoas, c, buffer: float = 5.0) -> Lis
 def equations(vars, mic_positions, mic_pairs, tdoas, c, weights: Optional[np.ndarray] = None) -> List[float]:
     """Weighted range-difference residuals (d_j - d_i) - c td (utils.py:384-405), evaluated for all pairs at
     once (the reference loops in Python: 12.5 ms per call at 2016 pairs)."""
+    return list(residuals(vars, mic_positions, mic_pairs, tdoas, c, weights))
+
+
+def residuals(vars, mic_positions, mic_pairs, tdoas, c, weights: Optional[np.ndarray] = None) -> np.ndarray:
+    """`equations` as an array (what the solver iterates on)."""
     if weights is not None and len(weights) != len(mic_pairs):
         raise ValueError("length of weights must equal the number of mic pairs")
     mics = np.asarray(mic_positions, dtype=np.float64)
@@ -251,7 +275,21 @@ def equations(vars, mic_positions, mic_pairs, tdoas, c, weights: Optional[np.nda
     res = (ranges[pairs[:, 1]] - ranges[pairs[:, 0]]) - c * np.asarray(tdoas, dtype=np.float64)[: pairs.shape[0]]
     if weights is not None:
         res = res * np.asarray(weights)
-    return list(res)
+    return res
+
+
+def equations_jacobian(vars, mic_positions, mic_pairs, tdoas, c, weights: Optional[np.ndarray] = None) -> np.ndarray:
+    """Analytic Jacobian of `equations`: d/dx (|x - m_j| - |x - m_i|) w = ((x - m_j) / d_j - (x - m_i) / d_i) w, [P][3].
+    The reference lets least_squares difference the residuals (three extra evaluations of its Python loop per step)."""
+    mics = np.asarray(mic_positions, dtype=np.float64)
+    pairs = np.asarray(mic_pairs, dtype=np.int64).reshape(-1, 2)
+    diff = np.asarray(vars, dtype=np.float64) - mics
+    ranges = np.sqrt(np.sum(diff ** 2, axis=1))
+    unit = diff / np.where(ranges > 0, ranges, 1.0)[:, None]
+    jac = unit[pairs[:, 1]] - unit[pairs[:, 0]]
+    if weights is not None:
+        jac = jac * np.asarray(weights)[:, None]
+    return jac
 
 
 def compute_weights(correlation_metrics, mic_pairs) -> np.ndarray:

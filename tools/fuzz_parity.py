@@ -15,7 +15,7 @@ bad = ties = rows = 0
 t0 = time.time()
 for case in range(cases):
     L = int(rng.choice([rng.integers(2, 64), rng.integers(64, 700), rng.integers(700, 3000), rng.integers(3000, 9000),
-                        rng.choice([496, 11962, 15525, 22651, 44100])]))   # (Rader rows at 991 = 2 x 496 - 1, fused column pass with PAL_FUSED=1)
+                        rng.choice([496, 11962, 15525, 22651, 44100])]))   # (Rader rows at 991 = 2 x 496 - 1, fused column pass where the plan has N1 <= 89)
     mics = int(rng.integers(2, 7))
     fs = float(rng.choice([8000.0, 16000.0, 44100.0, 48000.0]))
     med = None if rng.random() < 0.4 else float(rng.choice([0.0005, 0.002, 0.01, 0.05]))
