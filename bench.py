@@ -79,6 +79,8 @@ def fp64_flops_per_pair(info: dict, mics: int, length: int):
 
 
 def cpu_info():
+    """(CPU model, cores this process may run on, cores worth using): the affinity mask of a GPU box lists every thread
+    of the host (256) while the box's share of it is 16 cores per GPU; a cgroup CPU quota, when set, is the hard bound."""
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -88,7 +90,17 @@ def cpu_info():
                     break
     except OSError:
         pass
-    return model, len(os.sched_getaffinity(0))
+    affinity = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = max(1, int(float(q) / float(period) + 0.5))
+    except (OSError, ValueError):
+        pass
+    share = int(os.environ.get("PAL_BENCH_CPU_CORES", "0")) or min(affinity, quota if quota else 16)
+    return model, affinity, share
 
 
 _SHARED = {}          # frame 0 for the forked pool workers (copy-on-write: nothing is pickled per task)
@@ -117,23 +129,27 @@ def cpu_baseline(frame0: np.ndarray, fs: float, med, cpu_mics: int, budget_s: fl
     want = O.all_pairs(frame0[:cm], fs, max_expected_delay=med)
     one_s = time.perf_counter() - t1
     cpairs = cm * (cm - 1) // 2
-    model, cores = cpu_info()
+    model, affinity, cores = cpu_info()
     rate1 = cpairs / one_s
-    # all cores: as many pairs of the same frame as fit the time budget at the single-core rate
+    # all cores: blocks of four pairs of the same frame handed to a process pool until the time budget is spent
     full = [(i, j) for i in range(m) for j in range(i + 1, m)]
-    take = int(min(len(full), max(cores * 4, rate1 * cores * budget_s * 0.8)))
-    blocks = [full[k::cores * 4] for k in range(cores * 4)]
-    blocks = [b[: max(1, take // (cores * 4))] for b in blocks if b]
-    npool = sum(len(b) for b in blocks)
-    all_rate, all_s = None, None
+    blocks = [full[k: k + 4] for k in range(0, len(full), 4)]
+    all_rate, all_s, npool = None, None, 0
     try:
         _SHARED["frame0"] = frame0
         ctx = mp.get_context("fork")                              # (no GPU state exists yet in this process)
-        with ctx.Pool(cores) as pool:
+        pool = ctx.Pool(cores)
+        try:
             pool.map(_cpu_pairs, [(b[:1], fs, med) for b in blocks[:cores]])      # imports + FFT plans
             t2 = time.perf_counter()
-            pool.map(_cpu_pairs, [(b, fs, med) for b in blocks])
+            for done in pool.imap_unordered(_cpu_pairs, [(b, fs, med) for b in blocks]):
+                npool += len(done)
+                if time.perf_counter() - t2 > budget_s:
+                    break
             all_s = time.perf_counter() - t2
+        finally:
+            pool.terminate()
+            pool.join()
         all_rate = npool / all_s
     except Exception as exc:                                      # reported, never silent
         print(f"[bench] all-cores CPU leg failed: {exc}", file=sys.stderr)
@@ -142,7 +158,8 @@ def cpu_baseline(frame0: np.ndarray, fs: float, med, cpu_mics: int, budget_s: fl
                      "3 exact-length FFTs per pair like utils.py:114-118)",
            "all_cores": {"value": round(all_rate, 2) if all_rate else None, "cores": cores,
                          "sample": f"{npool} pairs of frame 0 over a pool of {cores} processes ({all_s:.1f} s)" if all_s else "failed"},
-           "cpu_model": model, "host_cores": cores}
+           "cpu_model": model, "host_cores_visible": affinity,
+           "cores_note": "pool size = the box's CPU share per GPU (16) or its cgroup quota; the affinity mask lists the whole host"}
     return cpu, want, cm
 
 

@@ -72,7 +72,7 @@ def test_c3_sixteen_trial_batch(engine, golden):
             n = 2 * length - 1
             i, j = np.triu_indices(64, k=1)
             for t in (1, 7, 15):
-                want = (offsets[t][i] - offsets[t][j]) % n
+                want = (offsets[t][j] - offsets[t][i]) % n
                 assert np.count_nonzero(tb[t]["k_argmax"] == want) >= 2000, t
     again = engine.gcc_phat_all_pairs(batch, fs, max_expected_delay=0.05)
     assert again.tobytes() == engine.gcc_phat_all_pairs(batch, fs, max_expected_delay=0.05).tobytes()
