@@ -101,10 +101,14 @@ static int check_status(Engine* e) {
   int rc = e->check(hipMemcpy(&st, e->ws[7], sizeof st, hipMemcpyDeviceToHost), "status read");
   if (rc != PAL_OK) return rc;
   if (getenv("PAL_DEBUG_FALLBACK")) {   // diagnostics: rows whose median needed the radix select since the last report
-    int slow = 0;
+    int slow = 0, exact = 0;
     if (hipMemcpy(&slow, static_cast<int*>(e->ws[7]) + 1, sizeof slow, hipMemcpyDeviceToHost) == hipSuccess && slow) {
       fprintf(stderr, "[pal] %d row(s) took the radix-select fallback\n", slow);
       hipMemset(static_cast<int*>(e->ws[7]) + 1, 0, sizeof slow);
+    }
+    if (hipMemcpy(&exact, static_cast<int*>(e->ws[7]) + 3, sizeof exact, hipMemcpyDeviceToHost) == hipSuccess && exact) {
+      fprintf(stderr, "[pal] %d row(s) needed the exact median (a threshold comparison inside the histogram interval)\n", exact);
+      hipMemset(static_cast<int*>(e->ws[7]) + 3, 0, sizeof exact);
     }
   }
   int in = 0;                                // word 2: input problems found by device-side checks

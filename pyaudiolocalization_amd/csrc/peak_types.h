@@ -18,12 +18,37 @@ struct RowPre {                          // pivot launch -> the other two
 struct Partial {                         // one segment's share of the streaming pass
   double vmax, vmin, hb, s1, s2, a1, a2;
   double plat;                           // fused column pass only: highest sample with an equal neighbour (-inf: none)
-  double lo, hi;                         // fused column pass only: the pivots THIS segment used (its own block sample); `below`
-                                         // counts its values under lo, its share of the row's list holds those in [lo, hi]
   double pfloor;                         // fused column pass only: samples of this segment below it had no peak test
   long long below;
   int imax, imin, mb, pad;
 };
+
+// Fused column pass: a column block's histogram of |x| around ITS median, 128 logarithmic bins per octave (seven mantissa
+// bits) over the sixteen octaves below 1.0 (a PHAT sequence never exceeds 1).  Counts are exact; the finish launch adds
+// the blocks' windows where they overlap and reads off the bin that holds the row's median: a rigorous interval of
+// relative width 0.5 % - enough to decide every threshold comparison that is not inside it (the exact median is computed
+// from the row only when one is).
+constexpr int kLogBins = 2048;           // 128 bins per octave x 16 octaves
+constexpr int kWin = 48;                 // bins a block publishes (its median bin -24 .. +23; the blocks' medians differ by ~3 bins)
+struct BlockHist {
+  int win0;                              // first bin of the window
+  unsigned below;                        // samples of the block in bins under win0
+  unsigned total;                        // samples of the block
+  unsigned pad;
+  unsigned h[kWin];
+};
+
+__host__ __device__ inline int log_bin(double mag) {                    // bin 2047 = [2^(-1/128), 1) and everything above, bin 0 = everything below 2^-16
+  const long long bits = __builtin_bit_cast(long long, mag) & 0x7fffffffffffffffll;
+  const int key = int(bits >> 45);                                      // 11 exponent bits + 7 mantissa bits
+  const int b = key - (1023 * 128 - kLogBins);
+  return b < 0 ? 0 : (b > kLogBins - 1 ? kLogBins - 1 : b);
+}
+__host__ __device__ inline double log_bin_floor(int b) {                // smallest magnitude of bin b (0 for bin 0, infinity past the last)
+  if (b <= 0) return 0.0;
+  if (b > kLogBins - 1) return __builtin_huge_val();
+  return __builtin_bit_cast(double, (long long)(b + (1023 * 128 - kLogBins)) << 45);
+}
 
 struct PeakArgs {
   const double* corr;
@@ -32,7 +57,9 @@ struct PeakArgs {
   double fs, mult, med;   // med: NaN = no window
   int method, dist, num_peaks, snr_w;   // method: 0 median, 1 adaptive, < 0 metrics only
   int splits, tiles_per_seg;             // segments per row, tiles per segment
-  int local_pivots;                      // 1: every segment brought its own pivots (Partial.lo / hi / pfloor), no RowPre
+  int local_pivots;                      // 1: fused column pass - no RowPre, no bracket lists: every segment brought a histogram
+                                         //    window (BlockHist) and its own bound for untested samples (Partial.pfloor)
+  BlockHist* bh;                         // [rows][splits] (local_pivots only)
   int edge_n2;                           // > 0: segments are column blocks of the prime-factor grid (row length edge_n2);
                                          //      the finish launch tests the samples of columns 0 and edge_n2 - 1 itself
   RowPre* pre;                           // [rows]

@@ -57,6 +57,8 @@ constexpr int kBins = 2048;       // histogram bins (sample pivots, list search,
 constexpr int kSmall = 1024;      // exact rank search capacity
 constexpr int kMemo = 1024;       // resolved peaks remembered per selection
 constexpr int kStack = 64;        // depth of the suppression recursion
+constexpr int kFusedColsOwn = 62; // columns per block of the fused column pass (pfa_cols_stats.h kColsOwn)
+constexpr int kMaxStaged = 40;    // segments whose results the finish launch stages through LDS (the fused column pass has at most ceil(2048 / 62) = 34 blocks)
 constexpr int kUnroll = 4;        // 16-byte loads in flight per lane
 constexpr int kTile = kTS * kUnroll;   // element pairs per tile of the stream
 
@@ -202,13 +204,13 @@ __device__ __forceinline__ bool peak_mid(const double* c, int n, int m, double& 
   return true;
 }
 
+__device__ bool small_rank(Shared& s, int tid, unsigned inner, double& out);
+
 // ---- exact rank inside the row's bracket list (global memory, L2-resident) whose values lie in [lo, hi] ----
 // linear bins spread the bracket over the histogram; the winning bin (a handful of values) is ranked by counting.
 // returns false when that bin is too crowded for the exact search (caller falls back to the radix select)
-// `flo` / `fhi`: only list values inside [flo, fhi] take part (the fused column pass lists per-segment brackets; the
-// median is searched in their intersection); `rank` counts inside that filtered set.
 __device__ bool list_select(Shared& s, int tid, const double* __restrict__ list, int cnt, unsigned rank, double lo, double hi,
-                            double& out, double flo = -INFINITY, double fhi = INFINITY) {
+                            double& out) {
   constexpr int kKeep = 16;                                    // list values a lane keeps in registers between the two passes
   for (int k = tid; k < kBins; k += kT) s.hist[k] = 0;
   if (tid == 0) s.count2 = 0;
@@ -225,14 +227,10 @@ __device__ bool list_select(Shared& s, int tid, const double* __restrict__ list,
     const int e = tid + q * kT;
     keep[q] = e < cnt ? list[e] : 0.0;
   }
-  auto pass = [&](double v) { return v >= flo && v <= fhi; };
 #pragma unroll
   for (int q = 0; q < kKeep; ++q)
-    if (tid + q * kT < cnt && pass(keep[q])) atomicAdd(&s.hist[bin_of(keep[q])], 1u);
-  for (int e = tid + kKeep * kT; e < cnt; e += kT) {
-    const double v = list[e];
-    if (pass(v)) atomicAdd(&s.hist[bin_of(v)], 1u);
-  }
+    if (tid + q * kT < cnt) atomicAdd(&s.hist[bin_of(keep[q])], 1u);
+  for (int e = tid + kKeep * kT; e < cnt; e += kT) atomicAdd(&s.hist[bin_of(list[e])], 1u);
   __syncthreads();
   unsigned bin, inner, pop;
   find_bin(s, tid, rank, bin, inner, pop);
@@ -240,19 +238,25 @@ __device__ bool list_select(Shared& s, int tid, const double* __restrict__ list,
   // the winning bin holds a handful of values: a lane that owns one takes a slot with its own LDS atomic
 #pragma unroll
   for (int q = 0; q < kKeep; ++q)
-    if (tid + q * kT < cnt && pass(keep[q]) && unsigned(bin_of(keep[q])) == bin) {
+    if (tid + q * kT < cnt && unsigned(bin_of(keep[q])) == bin) {
       const int at = atomicAdd(&s.count2, 1);
       if (at < kSmall) s.small[at] = keep[q];
     }
   for (int e = tid + kKeep * kT; e < cnt; e += kT) {
     const double v = list[e];
-    if (pass(v) && unsigned(bin_of(v)) == bin) {
+    if (unsigned(bin_of(v)) == bin) {
       const int at = atomicAdd(&s.count2, 1);
       if (at < kSmall) s.small[at] = v;
     }
   }
   __syncthreads();
-  const int m = s.count2 < kSmall ? s.count2 : kSmall;
+  return small_rank(s, tid, inner, out);
+}
+
+// exact value of 0-based rank `inner` among the s.count2 values collected in s.small (false: more than its capacity)
+__device__ bool small_rank(Shared& s, int tid, unsigned inner, double& out) {
+  if (s.count2 > kSmall) { __syncthreads(); return false; }
+  const int m = s.count2;
   for (int e = tid; e < m; e += kT) {
     const double v = s.small[e];
     unsigned below = 0;
@@ -266,6 +270,28 @@ __device__ bool list_select(Shared& s, int tid, const double* __restrict__ list,
   out = s.bc_d[0];
   __syncthreads();
   return true;
+}
+
+// Exact order statistic `rank_in` (0-based, counted inside the interval) of |c| among the row's samples with
+// lo <= |c| < hi: one pass over the stored row.  The fused column pass knows the interval from its histograms (about
+// 0.2 % of the row); used only when a threshold comparison falls inside mult x that interval.
+__device__ bool interval_select(Shared& s, int tid, const double* __restrict__ c, int n, double lo, double hi, unsigned rank_in,
+                                double& out) {
+  if (tid == 0) s.count2 = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 4 * kT) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kT + tid;
+      v[u] = i < n ? fabs(c[i]) : -1.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) append(v[u] >= lo && v[u] < hi, v[u], s.small, &s.count2, kSmall, tid & 63);
+  }
+  __syncthreads();
+  if (unsigned(s.count2) <= rank_in) { __syncthreads(); return false; }
+  return small_rank(s, tid, rank_in, out);
 }
 
 // ---- fallback: radix select over the 63 magnitude bits, re-reading the row ----
@@ -438,9 +464,12 @@ __device__ __forceinline__ bool next_candidate(const SelArgs a, const double* c,
   return bm >= 0;
 }
 
-// top-num_peaks kept peaks >= thr in the window; returns count or -1 on overflow
-__device__ __forceinline__ int select_peaks(const SelArgs a, const double* c, int tid, Shared& s, double thr, bool windowed, int wlo,
-                            int whi, double first_h, int first_m) {
+// top-num_peaks kept peaks >= thr in the window; returns count or -1 on overflow.  The threshold may be known as an
+// interval only (tlo <= thr <= thi, fused column pass): candidates arrive in descending height, one at or above thi
+// passes, one below tlo ends the search, and for one in between the function returns -2: the caller makes the
+// threshold exact (tlo == thi) and calls again.
+__device__ __forceinline__ int select_peaks(const SelArgs a, const double* c, int tid, Shared& s, double tlo, double thi,
+                            bool windowed, int wlo, int whi, double first_h, int first_m) {
   if (tid == 0) s.memo_n = 0;
   __syncthreads();
   double bound_h = INFINITY;
@@ -452,8 +481,9 @@ __device__ __forceinline__ int select_peaks(const SelArgs a, const double* c, in
     int cm;
     if (use_first) {
       ch = first_h; cm = first_m; use_first = false;
-    } else if (!next_candidate(a, c, tid, s, thr, windowed, wlo, whi, bound_h, bound_m, ch, cm)) {
-      break;
+    } else {
+      if (!next_candidate(a, c, tid, s, tlo, windowed, wlo, whi, bound_h, bound_m, ch, cm)) break;
+      if (!(ch >= thi)) return -2;                             // inside the threshold's interval (never when tlo == thi)
     }
     const int st = resolve(c, a.n, a.dist, tid, s, cm, ch);
     if (st < 0) return -1;
@@ -826,13 +856,14 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
     pt.vmax = vmax; pt.vmin = vmin; pt.hb = hb; pt.s1 = sums[0]; pt.s2 = sums[1]; pt.a1 = sums[2]; pt.a2 = sums[3];
     pt.below = (long long)sums[4]; pt.imax = imax; pt.imin = imin; pt.mb = mb; pt.pad = 0;
     pt.plat = -INFINITY;
-    pt.lo = 0; pt.hi = INFINITY; pt.pfloor = -INFINITY;        // (the row's pivots come from the pivot launch on this path)
+    pt.pfloor = -INFINITY;                                     // (the row's bounds come from the pivot launch on this path)
     a.parts[size_t(row) * S + seg] = pt;
   }
 }
 
 // ------------------------------------------------------------------ 3. finish
-__global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record* table, int32_t* ksel_multi, int* status) {
+template <bool LOCAL>   // LOCAL: the segments are column blocks of the fused column pass (histogram windows, no pivots)
+__global__ __launch_bounds__(kT, 4) void k_peak_finish(PeakArgs a, pal_pair_record* table, int32_t* ksel_multi, int* status) {   // (4 waves per SIMD = two workgroups per CU: the launch is latency-bound)
   __shared__ Shared s;
   const int tid = threadIdx.x;
   const int S = a.splits;
@@ -840,12 +871,11 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   const double* c = a.corr + size_t(row) * a.stride;
   const int n = a.n;
   const bool want_median = a.method == 0;
-  const bool local = a.local_pivots != 0;                     // fused column pass: zero shifts, per-segment pivots (Partial)
+  constexpr bool local = LOCAL;                               // fused column pass: zero shifts, no row parameters
   RowPre pre;
   if (local) { pre.k0 = pre.ka = 0; pre.lo = 0; pre.hi = INFINITY; pre.vfloor = pre.pfloor = -INFINITY; }
   else pre = load_pre(a.pre, row);
-  const double k0 = pre.k0, ka = pre.ka;
-  double lo = pre.lo, hi = pre.hi;
+  const double k0 = pre.k0, ka = pre.ka, lo = pre.lo, hi = pre.hi;
   const unsigned r1 = unsigned((n - 1) / 2), r2 = unsigned(n / 2);   // ranks of the median's one or two order statistics
   int stamp_at = 0;
   auto stamp = [&]() {
@@ -859,24 +889,27 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
   double vmax = 0, vmin = 0, hb = 0, s1 = 0, s2 = 0, a1 = 0, a2 = 0;
   long long below = 0;
   double plat = -INFINITY;
+  // (the segments' results are staged through LDS in one round of loads: a loop of global loads over sixteen column
+  //  blocks costs sixteen dependent round trips in this latency-bound launch)
+  __shared__ Partial sparts[kMaxStaged];
+  const bool staged = S <= kMaxStaged;
+  if (staged) {
+    const double* src = reinterpret_cast<const double*>(a.parts + size_t(row) * S);
+    double* dst = reinterpret_cast<double*>(sparts);
+    for (int i = tid; i < S * int(sizeof(Partial) / sizeof(double)); i += kT) dst[i] = src[i];
+    __syncthreads();
+  }
   for (int q = 0; q < S; ++q) {
-    const Partial pt = a.parts[size_t(row) * S + q];
+    const Partial pt = staged ? sparts[q] : a.parts[size_t(row) * S + q];
     plat = fmax(plat, pt.plat);
     if (pt.imax >= 0 && (imax < 0 || arg_better<0>(pt.vmax, pt.imax, vmax, imax))) { vmax = pt.vmax; imax = pt.imax; }
     if (pt.imin >= 0 && (imin < 0 || arg_better<1>(pt.vmin, pt.imin, vmin, imin))) { vmin = pt.vmin; imin = pt.imin; }
     if (pt.mb >= 0 && (mb < 0 || higher(pt.hb, pt.mb, hb, mb))) { hb = pt.hb; mb = pt.mb; }
     s1 += pt.s1; s2 += pt.s2; a1 += pt.a1; a2 += pt.a2;
     below += pt.below;
-    if (local) {                                               // intersection of the segments' brackets; highest untested bound
-      lo = fmax(lo, pt.lo);
-      hi = fmin(hi, pt.hi);
-      pre.pfloor = fmax(pre.pfloor, pt.pfloor);
-    }
+    if (local) pre.pfloor = fmax(pre.pfloor, pt.pfloor);       // highest bound under which a segment left samples untested
   }
   stamp();
-  const int cnt = want_median ? a.gcount[row] : 0;
-  const double* list = a.glist + size_t(row) * kList;
-  const double mean_abs = ka + a1 / double(n);                 // np.mean(np.abs(corr)) (utils.py:155)
   if (imax < 0) {                                              // no sample reached the pivot launch's bound for the maximum (insurance): scan
     double bv = 0;
     int bi = -1;
@@ -917,10 +950,29 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
       if (em >= 0 && (mb < 0 || higher(eh, em, hb, mb))) { hb = eh; mb = em; }
       plat = fmax(plat, block_max<kNW>(tie, s.red_d, tid));
     }
-    // Rescan the row when a reported plateau may outrank the best strict peak, or when the best peak ends up below the
-    // pivot launch's bound (the segments only tested samples above it: then it was not a bound - cannot happen while the
-    // bound is a value of the row itself, kept as insurance)
-    if ((plat > -INFINITY && (mb < 0 || plat >= hb)) || (pre.pfloor > -INFINITY && (mb < 0 || hb < pre.pfloor))) {
+    if constexpr (local) {
+      // A column block tested only its samples at or above 0.8 x ITS maximum.  Where that maximum is no peak at all (an
+      // end point of the row, or a sample beside a higher one in the next block) and the row's best peak so far is
+      // lower than the block's bound, the block's untested samples may hold a higher peak: test that block again, all of
+      // it (62 columns x N1 output indices; about one row in a hundred - e.g. the zero-lag maximum of two microphones
+      // with equal delays sits at index 0, which is never a peak).
+      const int N2 = a.edge_n2, N1 = N2 > 0 ? n / N2 : 0;
+      for (int q = 0; q < S && N2 > 0; ++q) {
+        const double pf = staged ? sparts[q].pfloor : a.parts[size_t(row) * S + q].pfloor;
+        if (!(pf > -INFINITY) || (mb >= 0 && hb >= pf)) continue;          // (uniform)
+        const int c0 = q * kFusedColsOwn, cols = N2 - c0 < kFusedColsOwn ? N2 - c0 : kFusedColsOwn;
+        eh = 0;
+        em = -1;
+        for (int k = tid; k < cols * N1; k += kT) test(c0 + k % cols + N2 * (k / cols), eh, em);
+        barg<2>(eh, em, s, tid);
+        if (em >= 0 && (mb < 0 || higher(eh, em, hb, mb))) { hb = eh; mb = em; }
+        plat = fmax(plat, block_max<kNW>(tie, s.red_d, tid));
+      }
+    }
+    // Rescan the row when a reported plateau may outrank the best strict peak, or (separate launches) when the best peak
+    // ends up below the pivot launch's bound (the segments only tested samples above it: then it was not a bound -
+    // cannot happen while the bound is a value of the row itself, kept as insurance)
+    if ((plat > -INFINITY && (mb < 0 || plat >= hb)) || (!local && pre.pfloor > -INFINITY && (mb < 0 || hb < pre.pfloor))) {
       eh = 0;
       em = -1;
       for (int m = 1 + tid; m <= n - 2; m += kT) test(m, eh, em);
@@ -974,55 +1026,68 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
     return;
   }
 
-  // ---- primary threshold (utils.py:144-149) ----
-  double thr1;
+  // ---- primary threshold (utils.py:144-149): exact, or (fused column pass) an interval [tlo, thi] that holds it ----
+  double tlo, thi;
+  unsigned rin1 = 0, rin2 = 0;                                 // ranks of the median's order statistics inside their bins
+  double b1lo = 0, b1hi = 0, b2lo = 0, b2hi = 0;               // those bins
+  bool have_bins = false;
   if (want_median) {
-    double m0 = 0, m1 = 0;
-    bool ok;
-    if (local) {
-      // Every segment listed its values inside its OWN bracket [lo_s, hi_s] and counted those below lo_s.  Inside the
-      // intersection [lo, hi] = [max lo_s, min hi_s] the union of the lists is complete; below it are the segments'
-      // counts plus the listed values under lo.
-      ok = cnt >= 0 && cnt <= kList && lo <= hi;
-      long long under = 0, inside = 0;
-      if (ok) {
-        long long u = 0, in = 0;
-        for (int e = tid; e < cnt; e += kT) {
-          const double v = list[e];
-          u += v < lo;
-          in += v >= lo && v <= hi;
-        }
-        under = bsum_ll(u, s, tid);
-        __syncthreads();
-        inside = bsum_ll(in, s, tid);
-        __syncthreads();
-        const long long base = below + under;
-        ok = (long long)r1 >= base && (long long)r2 < base + inside;
-        if (ok) ok = list_select(s, tid, list, cnt, unsigned(r1 - base), lo, hi, m0, lo, hi);
-        if (ok) { m1 = m0; if (r2 != r1) ok = list_select(s, tid, list, cnt, unsigned(r2 - base), lo, hi, m1, lo, hi); }
+    if constexpr (local) {
+      // Every segment published the counts of 48 histogram bins around its own median and the count below them.  Where
+      // the windows overlap the sums are the row's exact counts: the bin that holds rank r is a rigorous interval for
+      // that order statistic (relative width 2^(1/128) - 1 = 0.5 %).
+      const BlockHist* bh = a.bh + size_t(row) * S;
+      // headers first (one lane per segment), then every (segment, bin) entry by its own lane: two rounds of loads
+      __shared__ int swin0[kMaxStaged];
+      if (tid < 2 * kWin) s.hist[tid] = 0;                     // [0, kWin): merged bins of the common window; [kWin]: count below it; [kWin + 1]: total
+      if (tid < S && tid < kMaxStaged) swin0[tid] = bh[tid].win0;
+      __syncthreads();
+      int w0 = 0, w1 = kLogBins;
+      for (int q = 0; q < S && q < kMaxStaged; ++q) {
+        const int v = swin0[q];
+        w0 = v > w0 ? v : w0;
+        w1 = v + kWin < w1 ? v + kWin : w1;
       }
-    } else {
-      ok = cnt >= 0 && cnt <= kList && (long long)r1 >= below && (long long)r2 < below + cnt;
-      if (ok) ok = list_select(s, tid, list, cnt, unsigned(r1 - below), lo, hi, m0);
-      if (ok) { m1 = m0; if (r2 != r1) ok = list_select(s, tid, list, cnt, unsigned(r2 - below), lo, hi, m1); }
+      if (S > kMaxStaged) w1 = w0;                             // (guard: more segments than staged - the exact select decides)
+      if (tid < S && tid < kMaxStaged) {
+        atomicAdd(&s.hist[kWin], bh[tid].below);
+        atomicAdd(&s.hist[kWin + 1], bh[tid].total);
+      }
+      for (int e = tid; e < S * kWin && S <= kMaxStaged; e += kT) {
+        const int q = e / kWin, k = e - q * kWin;
+        const int b = swin0[q] + k;
+        const unsigned v = bh[q].h[k];
+        if (b < w0) atomicAdd(&s.hist[kWin], v);
+        else if (b < w1) atomicAdd(&s.hist[b - w0], v);
+      }
+      __syncthreads();
+      const unsigned total = s.hist[kWin + 1];
+      const unsigned base = s.hist[kWin];
+      have_bins = w0 < w1 && total == unsigned(n) && r1 >= base;
+      if (have_bins) {
+        unsigned e = base;
+        int f1 = -1, f2 = -1;
+        for (int k = 0; k < w1 - w0; ++k) {
+          const unsigned v = s.hist[k];
+          if (f1 < 0 && r1 < e + v) { f1 = k; rin1 = r1 - e; }
+          if (f2 < 0 && r2 < e + v) { f2 = k; rin2 = r2 - e; }
+          e += v;
+        }
+        have_bins = f1 >= 0 && f2 >= 0;
+        if (have_bins) {
+          b1lo = log_bin_floor(w0 + f1); b1hi = log_bin_floor(w0 + f1 + 1);
+          b2lo = log_bin_floor(w0 + f2); b2hi = log_bin_floor(w0 + f2 + 1);
+        }
+      }
+      __syncthreads();
     }
-    if (!ok && tid == 0) atomicAdd(status + 1, 1);             // diagnostics: rows that needed the slow exact select
-    if (!ok) {                                                 // pivots missed or a list overflowed: exact radix select
-      m0 = radix_select(c, n, tid, s, r1);
-      m1 = r2 != r1 ? radix_select(c, n, tid, s, r2) : m0;
+    if (have_bins) {                                           // np.median = the middle value, or the mean of the two middle ones
+      const double ml = r2 != r1 ? (b1lo + b2lo) * 0.5 : b1lo, mh = r2 != r1 ? (b1hi + b2hi) * 0.5 : b1hi;
+      tlo = a.mult >= 0 ? a.mult * ml : a.mult * mh;
+      thi = a.mult >= 0 ? a.mult * mh : a.mult * ml;
     }
-    thr1 = a.mult * (r2 != r1 ? (m0 + m1) * 0.5 : m0);         // np.median
-  } else {
-    double va = (a2 - a1 * a1 / double(n)) / double(n);
-    if (va < 0) va = 0;
-    thr1 = a.mult * (mean_abs + sqrt(va));                     // mean + std of |corr| (utils.py:147)
   }
-
   stamp();
-  // ---- fallback chain (utils.py:152-179) ----
-  int branch = 0;
-  int count = 0;
-  bool overflow = false;
   const bool windowed = !isnan(a.med);
   int wlo = 1, whi = n - 2;
   if (windowed) {
@@ -1032,24 +1097,95 @@ __global__ __launch_bounds__(kT) void k_peak_finish(PeakArgs a, pal_pair_record*
     wlo = flo > 1.0 ? (flo < double(n) ? int(flo) : n) : 1;
     whi = fhi < double(n - 2) ? (fhi > -1.0 ? int(fhi) : -1) : n - 2;
   }
-  double thr = thr1;
-  bool argmax_fallback = false;
-  if (!(mb >= 0 && hb >= thr1)) {                          // no peak reaches the primary threshold
-    branch |= PAL_BR_ALT_THRESHOLD;
-    thr = mean_abs;
-    if (!(mb >= 0 && hb >= mean_abs)) { branch |= PAL_BR_ARGMAX_NO_PEAKS; argmax_fallback = true; }
-  }
-  if (!argmax_fallback) {
-    const bool first_ok = !windowed;                       // unwindowed: the best peak is already known
-    const SelArgs sa{n, a.n2, a.dist, a.num_peaks, a.fs, a.med};
-    count = select_peaks(sa, c, tid, s, thr, windowed, wlo, whi, first_ok ? hb : 0.0, first_ok ? mb : -1);
-    if (count < 0) overflow = true;
-    if (count == 0 && windowed) {
-      branch |= PAL_BR_WINDOW_RETRY;
-      count = select_peaks(sa, c, tid, s, mean_abs, true, wlo, whi, 0.0, -1);
-      if (count < 0) overflow = true;
-      if (count == 0) { branch |= PAL_BR_ARGMAX_WINDOW; argmax_fallback = true; }
+  const SelArgs sa{n, a.n2, a.dist, a.num_peaks, a.fs, a.med};
+  // np.mean(np.abs(corr)) (utils.py:155): the alternative threshold of the fallback chain.  The fused column pass sums
+  // |x| only for the 'adaptive' method; the (rare) fallback branches sum it from the stored row.
+  double mean_abs = ka + a1 / double(n);
+  bool have_mean_abs = !(local && want_median);
+  int branch = 0, count = 0;
+  bool overflow = false, argmax_fallback = false;
+  // The fallback chain (utils.py:152-179) runs on the interval [tlo, thi] first; a comparison inside it (`ambiguous`)
+  // sends the row through the loop a second time with the exact primary threshold.
+  bool thr_exact = !(local && want_median && have_bins);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (attempt == 1 || thr_exact) {
+      if (!thr_exact || attempt == 0) {
+        // the exact primary threshold: mean + std of |corr|, or the median from the old launches' bracket list, or -
+        // fused column pass - one pass over the stored row for the bin that holds it
+        if (!want_median) {
+          double va = (a2 - a1 * a1 / double(n)) / double(n);
+          if (va < 0) va = 0;
+          tlo = thi = a.mult * ((ka + a1 / double(n)) + sqrt(va));      // utils.py:147
+        } else {
+          double m0 = 0, m1 = 0;
+          bool ok = false;
+          if constexpr (local) {
+            if (have_bins) {
+              ok = interval_select(s, tid, c, n, b1lo, b1hi, rin1, m0);
+              if (ok) { m1 = m0; if (r2 != r1) ok = interval_select(s, tid, c, n, b2lo, b2hi, rin2, m1); }
+            }
+            if (tid == 0) atomicAdd(status + (ok ? 3 : 1), 1);       // diagnostics: rows that needed the exact median / the radix select
+          } else {
+            const int cnt = a.gcount[row];
+            const double* list = a.glist + size_t(row) * kList;
+            ok = cnt >= 0 && cnt <= kList && (long long)r1 >= below && (long long)r2 < below + cnt;
+            if (ok) ok = list_select(s, tid, list, cnt, unsigned(r1 - below), lo, hi, m0);
+            if (ok) { m1 = m0; if (r2 != r1) ok = list_select(s, tid, list, cnt, unsigned(r2 - below), lo, hi, m1); }
+            if (!ok && tid == 0) atomicAdd(status + 1, 1);           // diagnostics: rows that needed the slow exact select
+          }
+          if (!ok) {                                                 // pivots / windows missed or a list overflowed: exact radix select
+            m0 = radix_select(c, n, tid, s, r1);
+            m1 = r2 != r1 ? radix_select(c, n, tid, s, r2) : m0;
+          }
+          tlo = thi = a.mult * (r2 != r1 ? (m0 + m1) * 0.5 : m0);    // np.median
+        }
+        thr_exact = true;
+      }
     }
+    branch = 0;
+    count = 0;
+    overflow = argmax_fallback = false;
+    bool alt = false;                                        // the search runs with mean(|corr|) instead of the primary threshold
+    bool reach = false;
+    if (mb >= 0) {
+      if (hb >= thi) reach = true;
+      else if (hb >= tlo) continue;                          // inside the interval: exact threshold, second round
+    }
+    if (!reach) {                                            // no peak reaches the primary threshold
+      branch |= PAL_BR_ALT_THRESHOLD;
+      alt = true;
+    }
+    if (alt || windowed) {                                   // (the window retry below may need it: one place for the row pass)
+      if (alt && !have_mean_abs) {
+        double acc = 0;
+        for (int i = tid; i < n; i += kT) acc += fabs(c[i]);
+        mean_abs = bsum(acc, s, tid) / double(n);
+        __syncthreads();
+        have_mean_abs = true;
+      }
+    }
+    if (alt && !(mb >= 0 && hb >= mean_abs)) { branch |= PAL_BR_ARGMAX_NO_PEAKS; argmax_fallback = true; }
+    if (!argmax_fallback) {
+      const bool first_ok = !windowed;                       // unwindowed: the best peak is already known
+      count = select_peaks(sa, c, tid, s, alt ? mean_abs : tlo, alt ? mean_abs : thi, windowed, wlo, whi, first_ok ? hb : 0.0,
+                           first_ok ? mb : -1);
+      if (count == -2) continue;                             // a candidate inside the interval: exact threshold, second round
+      if (count < 0) overflow = true;
+      if (count == 0 && windowed) {
+        branch |= PAL_BR_WINDOW_RETRY;
+        if (!have_mean_abs) {
+          double acc = 0;
+          for (int i = tid; i < n; i += kT) acc += fabs(c[i]);
+          mean_abs = bsum(acc, s, tid) / double(n);
+          __syncthreads();
+          have_mean_abs = true;
+        }
+        count = select_peaks(sa, c, tid, s, mean_abs, mean_abs, true, wlo, whi, 0.0, -1);
+        if (count < 0) overflow = true;
+        if (count == 0) { branch |= PAL_BR_ARGMAX_WINDOW; argmax_fallback = true; }
+      }
+    }
+    break;
   }
   if (argmax_fallback || overflow) {
     if (tid == 0) { s.sel_pos[0] = imax; s.sel_h[0] = vmax; }
@@ -1115,7 +1251,9 @@ int Engine::peaks_setup(const double* corr, size_t stride, int rows, int n, int 
   size_t off_pre = (size_t(rows) * sizeof(int) + 127) & ~size_t(127);
   size_t off_parts = (off_pre + size_t(rows) * sizeof(RowPre) + 127) & ~size_t(127);
   size_t off_list = (off_parts + size_t(rows) * a.splits * sizeof(Partial) + 127) & ~size_t(127);
-  const size_t total = off_list + (a.method == 0 ? size_t(rows) * kList * sizeof(double) : 0);
+  // (fused column pass: the segments' histogram windows take the place of the bracket lists)
+  const size_t total = off_list + (a.local_pivots ? size_t(rows) * a.splits * sizeof(BlockHist)
+                                                  : (a.method == 0 ? size_t(rows) * kList * sizeof(double) : 0));
   void* sp = nullptr;
   PAL_TRY(scratch(on == stream2 ? 9 : (on == stream3 ? 12 : 8), total, &sp));
   char* base = static_cast<char*>(sp);
@@ -1123,6 +1261,7 @@ int Engine::peaks_setup(const double* corr, size_t stride, int rows, int n, int 
   a.pre = reinterpret_cast<RowPre*>(base + off_pre);
   a.parts = reinterpret_cast<Partial*>(base + off_parts);
   a.glist = reinterpret_cast<double*>(base + off_list);
+  a.bh = reinterpret_cast<BlockHist*>(base + off_list);
   return PAL_OK;
 }
 
@@ -1139,7 +1278,8 @@ int Engine::peaks_finish(PeakArgs& a, int rows, pal_pair_record* table, int32_t*
   }
   {
     ProfScope ps(this, metrics_only ? "k_peak_finish(metrics)" : "k_peak_finish", on);
-    k_peak_finish<<<dim3(rows), dim3(kT), 0, on>>>(a, table, ksel_multi, status);
+    if (a.local_pivots) k_peak_finish<true><<<dim3(rows), dim3(kT), 0, on>>>(a, table, ksel_multi, status);
+    else k_peak_finish<false><<<dim3(rows), dim3(kT), 0, on>>>(a, table, ksel_multi, status);
     PAL_HIP(hipGetLastError());
   }
   if (want_stamps && !metrics_only) {      // diagnostics: median phase times of this launch (synchronises)

@@ -285,8 +285,9 @@ bool Engine::pfa_can_fuse(const Plan& pl) const {
   return fuse_peaks && f.on() && f.nch >= 1 && f.nch <= 4 && f.n2 >= 3;
 }
 
-// row pass, column pass + streaming statistics (every column block with its own pivots), finish: the peak selection of
-// one launch group without a pivot launch and without the separate read of its correlation rows (pfa_cols_stats.h)
+// row pass, column pass + streaming statistics (every column block publishes a histogram window around its median),
+// finish: the peak selection of one launch group without a pivot launch, without bracket lists and without the separate
+// read of its correlation rows (pfa_cols_stats.h)
 int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, double* corr, size_t stride,
                                  const int* zero_rows, const pal_phat_params& prm, int n2, pal_pair_record* table, int32_t* ksel_multi,
                                  hipStream_t on) {
@@ -294,7 +295,6 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
   const int nblk = (f.n2 + kColsOwn - 1) / kColsOwn;
   PeakArgs a;
   PAL_TRY(peaks_setup(corr, stride, rows, pl.n, n2, prm, nblk, f.n2, on, a));
-  PAL_HIP(hipMemsetAsync(a.gcount, 0, size_t(rows) * sizeof(int), on));     // the rows' bracket lists start empty
   PAL_TRY(pfa_rows(pl, permuted, quads, G, Y, on));
   {
     ProfScope ps(this, "k_pfa_cols_stats", on);

@@ -11,18 +11,19 @@
 //     parts) and all N1 output indices t, its four wavefronts four chunks of kPfaTC indices and their mirrors;
 //     lanes 0 and 63 compute the neighbouring blocks' border columns again, so that every owned sample has both
 //     neighbours m -/+ 1 = (m2 -/+ 1, t) one lane away (DPP wave shifts)
-//   - the pivots are the workgroup's OWN: pass A puts |x| of its ~5500 samples per row into a logarithmic histogram in
-//     LDS (32 bins per octave over 64 octaves below 1.0 - a PHAT sequence never exceeds 1) and takes the exact maximum;
-//     the bins that hold the local ranks cnt/2 -/+ (3 sqrt(cnt) + 8) give the bracket [lo, hi] of THIS block (6 sigma of
-//     a sample median's rank: about 9 % of the samples fall inside).  The finish launch intersects the blocks' brackets:
-//     inside [max lo, min hi] the union of the blocks' lists holds every sample of the row, the counts below it are the
-//     blocks' `below` plus the listed values under max lo, and the median is found by rank there (exact; a miss falls
-//     back to the radix select over the row).  No sample of the row is needed before this launch: the former pivot
-//     launch (a latency-bound pass over 12 % of Y) is gone.
-//   - pass B (same registers): stores, min, sums, count below / list between the pivots; the index bookkeeping of the
-//     maximum and of the highest strict peak sits behind a wave-uniform test against the block's exact maximum and
-//     0.8 of it (a sample below them can be neither the block's maximum nor, unless none of the samples above is a
-//     strict peak, its highest peak - the finish launch rescans a row whose best peak ends up below a block's bound)
+//   - the median of |corr| (utils.py:145) without pivots, lists or a second pass: pass A puts |x| of the block's ~5500
+//     samples per row into a logarithmic histogram in LDS (128 bins per octave over the 16 octaves below 1.0 - a PHAT
+//     sequence never exceeds 1; EXACT counts), finds the bin of the block's own median and publishes the 48 bins around
+//     it plus the count below them (BlockHist, 208 bytes).  The blocks' medians differ by a few bins, so their windows
+//     overlap around the ROW's median: the finish launch adds them up and gets the bin that holds it - a rigorous
+//     interval of relative width 0.5 %.  A threshold comparison whose peak height lies outside mult x that interval is
+//     decided; the exact median is computed from the stored row only for a comparison inside it (rare: the candidates
+//     the selection examines are the highest peaks, the median sits at 0.67 sigma).  Pass A also takes the exact
+//     maximum, the minimum and the sums (and sum |x| for the 'adaptive' threshold only).
+//   - pass B (same registers): stores; the index bookkeeping of the maximum and of the highest strict peak sits behind
+//     a wave-uniform test against the block's exact maximum and 0.8 of it (a sample below them can be neither the
+//     block's maximum nor, unless none of the samples above is a strict peak, its highest peak - the finish launch
+//     rescans a row whose best peak ends up below a block's bound)
 //   - the first and last column of the grid have their neighbours in another output index: their peak test is left
 //     to the finish launch (2 N1 samples per row), like the samples with an equal neighbour (plateaus), which are
 //     only reported
@@ -36,42 +37,24 @@
 
 namespace pal {
 
-constexpr int kColsOwn = 62;      // columns a workgroup of the fused column pass owns (64 lanes - two border lanes)
-constexpr int kColsList = 320;    // bracket values per wavefront and row (about 135 expected at 6 sigma of the block's rank)
-constexpr int kLogBins = 2048;    // 32 bins per octave x 64 octaves below 1.0
+constexpr int kColsOwn = 62;      // columns a workgroup of the fused column pass owns (64 lanes - two border lanes; peaks.hip kFusedColsOwn)
 
 struct ColsWaveResult {           // one wavefront's share of a row segment
   double vmax, vmin, hb, s1, s2, a1, plat;
-  int imax, mb, below, pad;
+  int imax, mb, pad0, pad1;
 };
 
 __device__ __forceinline__ double shfl_down_d(double v, int o) { return __shfl_down(v, o, 64); }
-
-// logarithmic bin of |x|: exponent and five mantissa bits, bin 2047 = [1, 1.03..) (and everything above), bin 0 =
-// everything below 2^-63 (zero included)
-__device__ __forceinline__ int log_bin(double mag) {
-  const int key = (__double2hiint(mag) & 0x7fffffff) >> 15;            // 11 exponent bits + 5 mantissa bits
-  const int b = key - (1023 * 32 - (kLogBins - 1));
-  return b < 0 ? 0 : (b > kLogBins - 1 ? kLogBins - 1 : b);
-}
-__device__ __forceinline__ double log_bin_floor(int b) {                // smallest magnitude of bin b (0 for bin 0)
-  if (b <= 0) return 0.0;
-  if (b > kLogBins - 1) return INFINITY;
-  return __hiloint2double((b + (1023 * 32 - (kLogBins - 1))) << 15, 0);
-}
 
 template <int TC, int UNR>
 __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride, int N1, int N2,
                                                         int G, int nch, const double* __restrict__ T, const int* __restrict__ zero_rows, PeakArgs pa,
                                                         int rows) {
-  __shared__ unsigned hist[2][kLogBins];
-  __shared__ double list[4][2][kColsList + 1];                // + one dump slot for the unconditional stores
+  __shared__ unsigned hist[2][kLogBins + 1];                  // + one dump bin for the lanes that own nothing
   __shared__ ColsWaveResult res[4][2];
-  __shared__ int lcount[4][2];
-  __shared__ int gbase[2];
   __shared__ double wmax[4][2];
   __shared__ unsigned wtot[4][2];
-  __shared__ int bins[2][2];                                  // [row][lower / upper]: histogram bins of the bracket
+  __shared__ int medbin[2];                                   // bin of the block's own median per row
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = wave;                                        // nch <= 4: one workgroup covers every output index
@@ -85,15 +68,15 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
   const cd* Yg = Y + size_t(g) * N1 * N2 + m2c;
   const int h = (N1 - 1) / 2;
   {                                                           // histograms of both rows start empty (the loads below are in flight meanwhile)
-    uint4* hz = reinterpret_cast<uint4*>(&hist[0][0]);
-#pragma unroll
-    for (int q = 0; q < 2 * kLogBins / 4 / 256; ++q) hz[tid + 256 * q] = make_uint4(0, 0, 0, 0);
+    unsigned* hz = &hist[0][0];
+    for (int q = tid; q < 2 * (kLogBins + 1); q += 256) hz[q] = 0;
   }
   double cx[TC], sy[TC], cy[TC], sx[TC];
   double sumx = 0, sumy = 0;
   cd y0 = mk(0, 0);
   if (active) pfa_cols_accumulate<TC, UNR>(Yg, N1, N2, nch, ch, T, y0, cx, sy, cy, sx, sumx, sumy);
   const bool want_median = pa.method == 0;
+  const bool want_abs = pa.method > 0;                        // 'adaptive': mean and std of |corr| (utils.py:147)
   {   // a pair with a silent microphone: the row is exactly zero in the reference (see k_pfa_cols)
     const double kp = zero_rows && zero_rows[2 * g] ? 0.0 : 1.0, kq = zero_rows && 2 * g + 1 < rows && zero_rows[2 * g + 1] ? 0.0 : 1.0;
     if (kp == 0.0) { y0.x = sumx = 0.0; }
@@ -120,24 +103,38 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
   };
   __syncthreads();                                             // the zeroed histograms are visible
 
-  // ---- pass A: the block's histogram of |x| and exact maximum, per row
+  // ---- pass A: histogram of |x| (exact counts), maximum, minimum, sums - everything that needs no index
   const int nrow = 2 * g + 1 < rows ? 2 : 1;                   // odd tail: the last transform carries one pair (uniform)
-  if (active) {
-    for (int r = 0; r < nrow; ++r) {
-      double vm = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    double vm = -INFINITY, vn = INFINITY, s1 = 0, s2 = 0, a1 = 0;
+    if (active && r < nrow) {
       each_sample(r, [&](double x, int, bool exists) {
         if (!exists) return;
-        vm = own ? fmax(vm, x) : vm;
-        if (want_median && own) atomicAdd(&hist[r][log_bin(fabs(x))], 1u);
+        vm = fmax(vm, x);
+        vn = fmin(vn, x);
+        s1 += x;
+        s2 = __builtin_fma(x, x, s2);
+        if (want_abs) a1 += fabs(x);
+        if (want_median) atomicAdd(&hist[r][own ? log_bin(fabs(x)) : kLogBins], 1u);   // (lanes that own nothing: the dump bin)
       });
-      for (int o = 32; o > 0; o >>= 1) vm = fmax(vm, shfl_down_d(vm, o));
-      if (lane == 0) wmax[wave][r] = vm;
     }
-  } else if (lane == 0) {
-    wmax[wave][0] = wmax[wave][1] = -INFINITY;
+    if (!own) { vm = -INFINITY; vn = INFINITY; s1 = s2 = a1 = 0; }
+    for (int o = 32; o > 0; o >>= 1) {
+      vm = fmax(vm, shfl_down_d(vm, o));
+      vn = fmin(vn, shfl_down_d(vn, o));
+      s1 += shfl_down_d(s1, o);
+      s2 += shfl_down_d(s2, o);
+      a1 += shfl_down_d(a1, o);
+    }
+    if (lane == 0) {
+      wmax[wave][r] = vm;
+      ColsWaveResult& w = res[wave][r];
+      w.vmin = vn; w.s1 = s1; w.s2 = s2; w.a1 = a1;
+    }
   }
   __syncthreads();
-  // ---- the bracket of this block: bins of the local ranks cnt/2 -/+ margin (every lane scans 8 bins of both rows)
+  // ---- the block's median bin per row (every lane scans 8 bins of both rows), then the window around it is published
   if (want_median) {
     constexpr int PER = kLogBins / 256;
     unsigned hv[2][PER], sum[2] = {0, 0};
@@ -151,53 +148,57 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
       if (lane >= o) { inc[0] += t0; inc[1] += t1; }
     }
     if (lane == 63) { wtot[wave][0] = inc[0]; wtot[wave][1] = inc[1]; }
-    if (tid < 4) bins[tid >> 1][tid & 1] = (tid & 1) ? kLogBins - 1 : 0;      // whole range unless a rank falls inside the counts
+    if (tid < 2) medbin[tid] = 0;
     __syncthreads();
+    unsigned ex[2], cnt[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      unsigned before = 0, cnt = 0;
-      for (int w = 0; w < 4; ++w) { before += w < wave ? wtot[w][r] : 0; cnt += wtot[w][r]; }
-      unsigned ex = before + inc[r] - sum[r];
-      const int margin = int(3.0f * sqrtf(float(cnt))) + 8;
-      const int mid = int(cnt >> 1);
-      const unsigned ra = unsigned(mid - margin > 0 ? mid - margin : 0);
-      const unsigned rb = unsigned(mid + margin < int(cnt) - 1 ? mid + margin : (cnt ? int(cnt) - 1 : 0));
+      unsigned before = 0;
+      cnt[r] = 0;
+      for (int w = 0; w < 4; ++w) { before += w < wave ? wtot[w][r] : 0; cnt[r] += wtot[w][r]; }
+      ex[r] = before + inc[r] - sum[r];                        // samples in the bins under this lane's first bin
+      const unsigned mid = cnt[r] >> 1;
+      unsigned e = ex[r];
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
-        if (hv[r][q] && ra >= ex && ra < ex + hv[r][q] && ra > 0) bins[r][0] = PER * tid + q;
-        if (hv[r][q] && rb >= ex && rb < ex + hv[r][q] && rb + 1 < cnt) bins[r][1] = PER * tid + q;
-        ex += hv[r][q];
+        if (hv[r][q] && mid >= e && mid < e + hv[r][q]) medbin[r] = PER * tid + q;
+        e += hv[r][q];
       }
     }
     __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (2 * g + r >= rows) continue;
+      int w0 = medbin[r] - kWin / 2;
+      w0 = w0 < 0 ? 0 : (w0 > kLogBins - kWin ? kLogBins - kWin : w0);
+      BlockHist* bh = pa.bh + size_t(2 * g + r) * pa.splits + cb;
+      // the lane whose bins straddle w0 knows the count under the window; lanes 0 .. kWin-1 copy the window's bins
+      if (w0 >= PER * tid && w0 < PER * tid + PER) {
+        unsigned below = ex[r];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) below += PER * tid + q < w0 ? hv[r][q] : 0u;
+        bh->win0 = w0; bh->below = below; bh->total = cnt[r]; bh->pad = 0;
+      }
+      if (tid < kWin) bh->h[tid] = hist[r][w0 + tid];
+    }
   }
 
-  // ---- pass B: stores and statistics, with the block's own pivots and bounds
+  // ---- pass B: stores, and the index bookkeeping of maximum / highest strict peak behind the block's exact bounds
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int row = 2 * g + r;
-    if (row >= rows) { if (lane == 0) lcount[wave][r] = 0; continue; }
-    const double lo = want_median ? log_bin_floor(bins[r][0]) : 0.0;
-    const double hi = want_median ? log_bin_floor(bins[r][1] + 1) : INFINITY;      // (inclusive upper pivot: the next bin's first value)
+    if (row >= rows) continue;
     const double vfloor = fmax(fmax(wmax[0][r], wmax[1][r]), fmax(wmax[2][r], wmax[3][r]));   // the block's exact maximum
     const double pfloor = vfloor > 0 ? 0.8 * vfloor : -INFINITY;
     double* const out = corr + size_t(row) * stride + m2c;
-    // Per-lane state.  A lane meets its samples in increasing lag order: the first maximum and the last peak of equal
-    // height win inside the lane, the merges compare indices.
-    double vmax = -INFINITY, vmin = INFINITY, hb = -INFINITY, plat = -INFINITY;
+    // A lane meets its samples in increasing lag order: the first maximum and the last peak of equal height win
+    // inside the lane, the merges compare indices.
+    double vmax = -INFINITY, hb = -INFINITY, plat = -INFINITY;
     int imax = -1, mb = -1;
-    double s1 = 0, s2 = 0, a1 = 0;
-    int below = 0, run = 0;                                    // wave-uniform counts
-    double* mylist = list[wave][r];
     if (active) {
       each_sample(r, [&](double x, int t, bool exists) {
         if (!exists) return;
         out[N2 * t] = x;                                       // (border lanes store the value their column's owner stores)
-        vmin = fmin(vmin, x);                                  // (lanes that own nothing are reset below)
-        const double mag = fabs(x);
-        s1 += x;
-        s2 = __builtin_fma(x, x, s2);
-        a1 += mag;
         if (__ballot((own && x >= vfloor) || (inner && x >= pfloor))) {
           const int m = m2 + N2 * t;
           const bool up = own && x > vmax;
@@ -211,41 +212,24 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
           // an equal pair (m - 1, m) is reported by its right element (here, or by the finish launch for the grid's edge columns)
           plat = inner && x >= pfloor && left == x ? fmax(plat, x) : plat;
         }
-        if (want_median) {
-          below += __popcll(__ballot(own && mag < lo));
-          const bool in = own && mag >= lo && mag <= hi;
-          const unsigned long long mask = __ballot(in);
-          const int at = run + int(__builtin_amdgcn_mbcnt_hi(unsigned(mask >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(mask), 0u)));
-          mylist[in ? min(at, kColsList) : kColsList] = mag;   // unconditional store, one dump slot
-          run += __popcll(mask);
-        }
       });
     }
-    if (!own) { vmin = INFINITY; s1 = s2 = a1 = 0; }
-    // wavefront reduction (lane 0 holds the result)
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 32; o > 0; o >>= 1) {                         // wavefront reduction (lane 0 holds the result)
       const double ov = shfl_down_d(vmax, o);
       const int oi = __shfl_down(imax, o, 64);
       if (oi >= 0 && (imax < 0 || ov > vmax || (ov == vmax && oi < imax))) { vmax = ov; imax = oi; }
       const double hv = shfl_down_d(hb, o);
       const int hi_ = __shfl_down(mb, o, 64);
       if (hi_ >= 0 && (mb < 0 || higher(hv, hi_, hb, mb))) { hb = hv; mb = hi_; }
-      vmin = fmin(vmin, shfl_down_d(vmin, o));
-      s1 += shfl_down_d(s1, o);
-      s2 += shfl_down_d(s2, o);
-      a1 += shfl_down_d(a1, o);
       plat = fmax(plat, shfl_down_d(plat, o));
     }
     if (lane == 0) {
-      ColsWaveResult w;
-      w.vmax = vmax; w.vmin = vmin; w.hb = hb; w.s1 = s1; w.s2 = s2; w.a1 = a1; w.plat = plat;
-      w.imax = imax; w.mb = mb; w.below = below; w.pad = 0;
-      res[wave][r] = w;
-      lcount[wave][r] = run;                                   // (> kColsList: the private list overflowed)
+      ColsWaveResult& w = res[wave][r];
+      w.vmax = vmax; w.hb = hb; w.plat = plat; w.imax = imax; w.mb = mb;
     }
   }
   __syncthreads();
-  // ---- publish: lanes 0 / 1 merge the four wavefronts of row p / q; the bracket values join the rows' global lists
+  // ---- publish: lanes 0 / 1 merge the four wavefronts of row p / q
   if (tid < 2 && 2 * g + tid < rows) {
     const int r = tid, row = 2 * g + r;
     Partial pt;
@@ -255,47 +239,19 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
     pt.s1 = pt.s2 = pt.a1 = pt.a2 = 0;
     pt.below = 0;
     pt.pad = 0;
-    int total = 0;
-    bool overflow = false;
     for (int w = 0; w < 4; ++w) {
       const ColsWaveResult x = res[w][r];
       if (x.imax >= 0 && (pt.imax < 0 || x.vmax > pt.vmax || (x.vmax == pt.vmax && x.imax < pt.imax))) { pt.vmax = x.vmax; pt.imax = x.imax; }
       pt.vmin = fmin(pt.vmin, x.vmin);
       if (x.mb >= 0 && (pt.mb < 0 || higher(x.hb, x.mb, pt.hb, pt.mb))) { pt.hb = x.hb; pt.mb = x.mb; }
       pt.s1 += x.s1; pt.s2 += x.s2; pt.a1 += x.a1;
-      pt.below += x.below;
       pt.plat = fmax(pt.plat, x.plat);
-      overflow = overflow || lcount[w][r] > kColsList;
-      total += lcount[w][r];
     }
     pt.a2 = pt.s2;                                              // sum |x|^2 = sum x^2 (both shifts are zero on this path)
     pt.imin = 0;                                                // (the finish launch only asks whether the segment has a minimum)
-    pt.lo = want_median ? log_bin_floor(bins[r][0]) : 0.0;
-    pt.hi = want_median ? log_bin_floor(bins[r][1] + 1) : INFINITY;
     const double bmax = fmax(fmax(wmax[0][r], wmax[1][r]), fmax(wmax[2][r], wmax[3][r]));
     pt.pfloor = bmax > 0 ? 0.8 * bmax : -INFINITY;
     pa.parts[size_t(row) * pa.splits + cb] = pt;
-    gbase[r] = want_median ? atomicAdd(&pa.gcount[row], overflow ? kList + 1 : total) : -1;   // an overflow poisons the list
-  }
-  __syncthreads();
-  if (want_median) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      if (2 * g + r >= rows) continue;
-      int before = 0, total = 0;
-      bool overflow = false;
-      for (int w = 0; w < 4; ++w) {
-        const int c = lcount[w][r];
-        overflow = overflow || c > kColsList;
-        before += w < wave ? c : 0;
-        total += c;
-      }
-      const int at = gbase[r];
-      if (overflow || at < 0 || at + total > kList) continue;
-      double* dst = pa.glist + size_t(2 * g + r) * kList + at + before;
-      const int mine = lcount[wave][r];
-      for (int k = lane; k < mine; k += 64) dst[k] = list[wave][r][k];
-    }
   }
 }
 
