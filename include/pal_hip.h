@@ -179,6 +179,12 @@ int pal_align_rows_dev(pal_handle h, const double* d_rows, int R, int N, const i
 int pal_filtfilt_dev(pal_handle h, const double* b, int nb, const double* a, int na, const double* zi, const double* d_rows,
                      int R, int N, double* d_out);
 int pal_wiener3_dev(pal_handle h, const double* d_rows, int R, int N, double* d_out);
+/* the same filter over R rows of DIFFERENT lengths in one launch (the frames of a stream have their own synchronised
+ * lengths, utils.py:448-456): row r is d_in[in_off[r] .. + lengths[r]) -> d_out[out_off[r] .. + lengths[r]) (host arrays
+ * of offsets in doubles and lengths).  One lane per row, 64 rows per wavefront: a launch takes the same time for 64 rows
+ * as for 65 536, so the caller batches. */
+int pal_filtfilt_ragged_dev(pal_handle h, const double* b, int nb, const double* a, int na, const double* zi, const double* d_in,
+                            double* d_out, int R, const int64_t* in_off, const int64_t* out_off, const int32_t* lengths);
 
 /* ---- multi-GPU: one gather of the TDOA table over RCCL/xGMI ------------------------------ */
 int pal_comm_unique_id(void* id128);                       /* rank 0; 128-byte ncclUniqueId          */

@@ -83,6 +83,8 @@ SIGNATURES = {
     "pal_filtfilt_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p]),
     "pal_wiener3_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pal_filtfilt_ragged_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "pal_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pal_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
     "pal_comm_all_gather": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -298,7 +298,13 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
   PAL_TRY(pfa_rows(pl, permuted, quads, G, Y, on));
   {
     ProfScope ps(this, "k_pfa_cols_stats", on);
-    k_pfa_cols_stats<kPfaTC, kPfaUnr><<<dim3(unsigned(G) * unsigned(nblk)), dim3(256), 0, on>>>(Y, corr, stride, f.n1, f.n2, G, f.nch, f.T, zero_rows, a, rows);
+    const dim3 grid(unsigned(G) * unsigned(nblk)), lanes(256);
+    const bool full = (f.n1 - 1) / 2 == f.nch * kPfaTC;          // every chunk index exists (N1 = 89: 44 = 4 x 11)
+    const bool adaptive = a.method > 0;
+#define PAL_COLS_STATS(AD, FU) k_pfa_cols_stats<kPfaTC, kPfaUnr, AD, FU><<<grid, lanes, 0, on>>>(Y, corr, stride, f.n1, f.n2, G, f.nch, f.T, zero_rows, a, rows)
+    if (adaptive) { if (full) PAL_COLS_STATS(true, true); else PAL_COLS_STATS(true, false); }
+    else { if (full) PAL_COLS_STATS(false, true); else PAL_COLS_STATS(false, false); }
+#undef PAL_COLS_STATS
     PAL_HIP(hipGetLastError());
   }
   return peaks_finish(a, rows, table, ksel_multi, on);

@@ -46,7 +46,22 @@ struct ColsWaveResult {           // one wavefront's share of a row segment
 
 __device__ __forceinline__ double shfl_down_d(double v, int o) { return __shfl_down(v, o, 64); }
 
-template <int TC, int UNR>
+// max / min without the canonicalising v_max_f64 x, x, x the compiler puts in front of every fmax / fmin (the inputs are
+// sums of finite products: there is no signalling NaN to quiet)
+__device__ __forceinline__ double max_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double min_raw(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// ADAPTIVE: threshold method 'adaptive' (mean + std of |corr|: sum |x| instead of the histogram).
+// FULL: every chunk index exists ((N1 - 1) / 2 == nch * TC, e.g. N1 = 89): no per-sample existence tests.
+template <int TC, int UNR, bool ADAPTIVE, bool FULL>
 __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride, int N1, int N2,
                                                         int G, int nch, const double* __restrict__ T, const int* __restrict__ zero_rows, PeakArgs pa,
                                                         int rows) {
@@ -67,7 +82,8 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
   const int m2c = m2 < 0 ? 0 : (m2 < N2 ? m2 : N2 - 1);       // border lanes outside the grid repeat its first / last column
   const cd* Yg = Y + size_t(g) * N1 * N2 + m2c;
   const int h = (N1 - 1) / 2;
-  {                                                           // histograms of both rows start empty (the loads below are in flight meanwhile)
+  constexpr bool want_median = !ADAPTIVE;
+  if (want_median) {                                          // histograms of both rows start empty (the loads below are in flight meanwhile)
     unsigned* hz = &hist[0][0];
     for (int q = tid; q < 2 * (kLogBins + 1); q += 256) hz[q] = 0;
   }
@@ -75,8 +91,6 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
   double sumx = 0, sumy = 0;
   cd y0 = mk(0, 0);
   if (active) pfa_cols_accumulate<TC, UNR>(Yg, N1, N2, nch, ch, T, y0, cx, sy, cy, sx, sumx, sumy);
-  const bool want_median = pa.method == 0;
-  const bool want_abs = pa.method > 0;                        // 'adaptive': mean and std of |corr| (utils.py:147)
   {   // a pair with a silent microphone: the row is exactly zero in the reference (see k_pfa_cols)
     const double kp = zero_rows && zero_rows[2 * g] ? 0.0 : 1.0, kq = zero_rows && 2 * g + 1 < rows && zero_rows[2 * g + 1] ? 0.0 : 1.0;
     if (kp == 0.0) { y0.x = sumx = 0.0; }
@@ -93,30 +107,40 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
 #pragma unroll
     for (int tt = 0; tt < TC; ++tt) {
       const int t = ch * TC + tt + 1;
-      fn(r ? base + cy[tt] + sx[tt] : base + cx[tt] - sy[tt], t, t <= h);
+      fn(r ? base + cy[tt] + sx[tt] : base + cx[tt] - sy[tt], t, FULL || t <= h);
     }
 #pragma unroll
     for (int tt = TC - 1; tt >= 0; --tt) {
       const int t = ch * TC + tt + 1;
-      fn(r ? base + cy[tt] - sx[tt] : base + cx[tt] + sy[tt], N1 - t, t <= h);
+      fn(r ? base + cy[tt] - sx[tt] : base + cx[tt] + sy[tt], N1 - t, FULL || t <= h);
     }
   };
   __syncthreads();                                             // the zeroed histograms are visible
 
   // ---- pass A: histogram of |x| (exact counts), maximum, minimum, sums - everything that needs no index
   const int nrow = 2 * g + 1 < rows ? 2 : 1;                   // odd tail: the last transform carries one pair (uniform)
+  // byte offset of a sample's bin inside its row's histogram: (key - kBase) * 4 clamped to the table, where key = the
+  // exponent and seven mantissa bits of |x| (log_bin); lanes that own nothing are lifted to the dump bin behind the table
+  constexpr unsigned kBase4 = unsigned(1023 * 128 - kLogBins) * 4u, kTop4 = kBase4 + unsigned(kLogBins - 1) * 4u;
+  const unsigned lift = own ? 0u : unsigned(kLogBins) * 4u;
+  const unsigned one = 1u;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     double vm = -INFINITY, vn = INFINITY, s1 = 0, s2 = 0, a1 = 0;
     if (active && r < nrow) {
+      char* const hrow = reinterpret_cast<char*>(&hist[r][0]);
       each_sample(r, [&](double x, int, bool exists) {
         if (!exists) return;
-        vm = fmax(vm, x);
-        vn = fmin(vn, x);
+        vm = max_raw(vm, x);
+        vn = min_raw(vn, x);
         s1 += x;
         s2 = __builtin_fma(x, x, s2);
-        if (want_abs) a1 += fabs(x);
-        if (want_median) atomicAdd(&hist[r][own ? log_bin(fabs(x)) : kLogBins], 1u);   // (lanes that own nothing: the dump bin)
+        if (ADAPTIVE) a1 += fabs(x);
+        if (want_median) {
+          const unsigned key4 = (unsigned(__double2hiint(x)) & 0x7fffe000u) >> 11;         // key * 4
+          const unsigned off = max(min(max(key4, kBase4), kTop4) - kBase4, lift);                    // (v_med3_u32)
+          atomicAdd(reinterpret_cast<unsigned*>(hrow + off), one);
+        }
       });
     }
     if (!own) { vm = -INFINITY; vn = INFINITY; s1 = s2 = a1 = 0; }
@@ -125,7 +149,7 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
       vn = fmin(vn, shfl_down_d(vn, o));
       s1 += shfl_down_d(s1, o);
       s2 += shfl_down_d(s2, o);
-      a1 += shfl_down_d(a1, o);
+      if (ADAPTIVE) a1 += shfl_down_d(a1, o);
     }
     if (lane == 0) {
       wmax[wave][r] = vm;
@@ -190,6 +214,9 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
     if (row >= rows) continue;
     const double vfloor = fmax(fmax(wmax[0][r], wmax[1][r]), fmax(wmax[2][r], wmax[3][r]));   // the block's exact maximum
     const double pfloor = vfloor > 0 ? 0.8 * vfloor : -INFINITY;
+    // one bound per lane: samples with both neighbours in their row are tested from 0.8 of the maximum on, the grid's
+    // edge columns only for the maximum itself, border lanes never
+    const double myfloor = inner ? pfloor : (own ? vfloor : INFINITY);
     double* const out = corr + size_t(row) * stride + m2c;
     // A lane meets its samples in increasing lag order: the first maximum and the last peak of equal height win
     // inside the lane, the merges compare indices.
@@ -199,7 +226,7 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
       each_sample(r, [&](double x, int t, bool exists) {
         if (!exists) return;
         out[N2 * t] = x;                                       // (border lanes store the value their column's owner stores)
-        if (__ballot((own && x >= vfloor) || (inner && x >= pfloor))) {
+        if (__ballot(x >= myfloor)) {
           const int m = m2 + N2 * t;
           const bool up = own && x > vmax;
           vmax = up ? x : vmax;

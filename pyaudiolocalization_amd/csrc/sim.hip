@@ -152,17 +152,44 @@ __device__ __forceinline__ double odd_ext(const double* x, int N, int edge, int 
   return 2 * x[N - 1] - x[N - 2 - (i - edge - N)];
 }
 
-// one lane per row; KT > 0: compile-time tap count with the state in registers, KT == 0: run-time
+// One lane per row (the recurrence is sequential along time and scipy's operation order is kept bit for bit), 64 rows
+// per wavefront.  The samples travel through LDS in tiles of 64: for every row of the tile the 64 lanes load 64
+// CONSECUTIVE samples (one coalesced 512-byte request instead of 64 lanes touching 64 cache lines per step, which left
+// the loop bound by one memory round trip per sample: 8 ms per launch), lane r then walks row r of the tile in LDS
+// (pitch 65: conflict-free), overwrites it with its outputs, and the tile goes back to memory coalesced the same way.
+// KT > 0: compile-time tap count with the state in registers, KT == 0: run-time (state in scratch memory).
+constexpr int kFiltTile = 64, kFiltPitch = kFiltTile + 1;
+
+// Rows may differ in length (`desc`: offsets of a row in x / out and its length; null: R rows of N samples back to back):
+// the frames of a stream have their own synchronised lengths (utils.py:448-456) and still share one launch.
+struct FiltRow { long long in_off, out_off; int n, pad; };
+
 template <int KT>
-__global__ __launch_bounds__(64) void k_filtfilt(const double* x, int R, int N, const double* b, const double* a,
-                                                 const double* zi, int K, double* tmp, double* out) {
-  const int r = blockIdx.x * 64 + threadIdx.x;
-  if (r >= R) return;
+__global__ __launch_bounds__(64) void k_filtfilt(const double* __restrict__ x, int R, int Nmax, const FiltRow* __restrict__ desc,
+                                                 const double* __restrict__ b, const double* __restrict__ a,
+                                                 const double* __restrict__ zi, int K, double* __restrict__ tmp,
+                                                 double* __restrict__ out) {
+  __shared__ double tile[64 * kFiltPitch];
+  __shared__ FiltRow rows[64];
+  const int lane = threadIdx.x;
+  const int r0 = blockIdx.x * 64;
+  const int r = r0 + lane;
+  const int nrow = R - r0 < 64 ? R - r0 : 64;                  // rows of this wavefront
+  const bool live = r < R;
   const int k = KT > 0 ? KT : K;
-  const int edge = 3 * k, len = N + 2 * edge;
-  const double* xr = x + size_t(r) * N;
-  double* tr = tmp + size_t(r) * len;
-  double* yr = out + size_t(r) * N;
+  const int edge = 3 * k;
+  {
+    FiltRow d;
+    if (desc) d = desc[live ? r : r0];
+    else { d.in_off = d.out_off = (long long)(live ? r : r0) * Nmax; d.n = Nmax; d.pad = 0; }
+    rows[lane] = d;
+  }
+  __syncthreads();
+  const int N = rows[lane].n, len = N + 2 * edge;              // this lane's own row
+  const size_t tstride = size_t(Nmax) + 2 * size_t(edge);      // rows of tmp
+  int lenmax = 0;
+  for (int q = 0; q < nrow; ++q) lenmax = rows[q].n + 2 * edge > lenmax ? rows[q].n + 2 * edge : lenmax;
+  const double* xr = x + rows[lane].in_off;
   constexpr int ZN = KT > 0 ? KT : 512;
   double z[ZN];
   double bb[KT > 0 ? KT : 1], aa[KT > 0 ? KT : 1];
@@ -170,40 +197,80 @@ __global__ __launch_bounds__(64) void k_filtfilt(const double* x, int R, int N, 
 #pragma unroll
     for (int q = 0; q < KT; ++q) { bb[q] = b[q]; aa[q] = a[q]; }
   }
+  auto step = [&](double xn) -> double {                       // scipy's DF2T lfilter step: multiply, then add
+    double yn;
+    if constexpr (KT > 0) {
+      yn = z[0] + bb[0] * xn;
+#pragma unroll
+      for (int q = 0; q < KT - 2; ++q) z[q] = z[q + 1] + xn * bb[q + 1] - yn * aa[q + 1];
+      z[KT - 2] = xn * bb[KT - 1] - yn * aa[KT - 1];
+    } else {
+      yn = z[0] + b[0] * xn;
+      for (int q = 0; q < k - 2; ++q) z[q] = z[q + 1] + xn * b[q + 1] - yn * a[q + 1];
+      z[k - 2] = xn * b[k - 1] - yn * a[k - 1];
+    }
+    return yn;
+  };
+  // ---- forward over the odd extension: tmp[i] for i < len
   const double x0 = odd_ext(xr, N, edge, 0);
   for (int q = 0; q < k - 1; ++q) z[q] = zi[q] * x0;
-  for (int i = 0; i < len; ++i) {
-    const double xn = odd_ext(xr, N, edge, i);
-    double yn;
-    if (KT > 0) {
-      yn = z[0] + bb[0] * xn;
+  for (int i0 = 0; i0 < lenmax; i0 += kFiltTile) {
+    for (int q0 = 0; q0 < nrow; q0 += 8) {                     // row q of the tile: 64 consecutive samples, one per lane;
+      double v[8];                                             // eight rows' loads in flight before the first LDS store
 #pragma unroll
-      for (int q = 0; q < KT - 2; ++q) z[q] = z[q + 1] + xn * bb[q + 1] - yn * aa[q + 1];
-      z[KT - 2] = xn * bb[KT - 1] - yn * aa[KT - 1];
-    } else {
-      yn = z[0] + b[0] * xn;
-      for (int q = 0; q < k - 2; ++q) z[q] = z[q + 1] + xn * b[q + 1] - yn * a[q + 1];
-      z[k - 2] = xn * b[k - 1] - yn * a[k - 1];
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + u < nrow ? q0 + u : nrow - 1;
+        const int nq = rows[q].n;
+        v[u] = (q0 + u < nrow && i0 + lane < nq + 2 * edge) ? odd_ext(x + rows[q].in_off, nq, edge, i0 + lane) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (q0 + u < nrow) tile[(q0 + u) * kFiltPitch + lane] = v[u];
     }
-    tr[i] = yn;
+    __syncthreads();
+    const int cnt = len - i0 < kFiltTile ? len - i0 : kFiltTile;   // (this lane's row; <= 0 behind its end)
+    if (live)
+      for (int j = 0; j < cnt; ++j) tile[lane * kFiltPitch + j] = step(tile[lane * kFiltPitch + j]);
+    __syncthreads();
+    for (int q = 0; q < nrow; ++q)
+      if (i0 + lane < rows[q].n + 2 * edge) tmp[size_t(r0 + q) * tstride + i0 + lane] = tile[q * kFiltPitch + lane];
+    __syncthreads();
   }
-  const double y0 = tr[len - 1];
+  // ---- backward over tmp (reversed): y[j] for the N samples inside the extension
+  const double y0 = live ? tmp[size_t(r) * tstride + len - 1] : 0.0;
   for (int q = 0; q < k - 1; ++q) z[q] = zi[q] * y0;
-  for (int i = len - 1; i >= 0; --i) {
-    const double xn = tr[i];
-    double yn;
-    if (KT > 0) {
-      yn = z[0] + bb[0] * xn;
+  for (int i0 = 0; i0 < lenmax; i0 += kFiltTile) {             // position p = len - 1 - i runs backwards through tmp
+    // Row q's tile holds tmp[len_q - 1 - (i0 + j)] at column j (cnt_q columns): lane l loads the ascending address
+    // len_q - cnt_q - i0 + l and puts it at column cnt_q - 1 - l
+    for (int q0 = 0; q0 < nrow; q0 += 8) {
+      double v[8];
+      int col[8];
 #pragma unroll
-      for (int q = 0; q < KT - 2; ++q) z[q] = z[q + 1] + xn * bb[q + 1] - yn * aa[q + 1];
-      z[KT - 2] = xn * bb[KT - 1] - yn * aa[KT - 1];
-    } else {
-      yn = z[0] + b[0] * xn;
-      for (int q = 0; q < k - 2; ++q) z[q] = z[q + 1] + xn * b[q + 1] - yn * a[q + 1];
-      z[k - 2] = xn * b[k - 1] - yn * a[k - 1];
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + u < nrow ? q0 + u : nrow - 1;
+        const int lq = rows[q].n + 2 * edge;
+        const int cq = lq - i0 < kFiltTile ? lq - i0 : kFiltTile;
+        const bool ok = q0 + u < nrow && lane < cq;
+        col[u] = ok ? cq - 1 - lane : -1;
+        v[u] = ok ? tmp[size_t(r0 + q) * tstride + (lq - cq - i0) + lane] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (col[u] >= 0) tile[(q0 + u) * kFiltPitch + col[u]] = v[u];
     }
-    const int j = i - edge;
-    if (j >= 0 && j < N) yr[j] = yn;
+    __syncthreads();
+    const int cnt = len - i0 < kFiltTile ? len - i0 : kFiltTile;
+    if (live)
+      for (int j = 0; j < cnt; ++j) tile[lane * kFiltPitch + j] = step(tile[lane * kFiltPitch + j]);
+    __syncthreads();
+    for (int q = 0; q < nrow; ++q) {
+      const int nq = rows[q].n, lq = nq + 2 * edge;
+      const int cq = lq - i0 < kFiltTile ? lq - i0 : kFiltTile;
+      const int p = (lq - cq - i0) + lane;                     // position of column cq - 1 - lane in the extended sequence
+      const int j = p - edge;
+      if (lane < cq && j >= 0 && j < nq) out[rows[q].out_off + j] = tile[q * kFiltPitch + (cq - 1 - lane)];
+    }
+    __syncthreads();
   }
 }
 
@@ -330,8 +397,9 @@ static int simulate_dev(Engine* e, const double* d_base, int bases, int nbase, d
 
 
 // filtfilt of rows[R][N] that already sit in HBM (b | a | zi normalised by a[0] are uploaded: 3 K doubles)
+// `rows` (host, optional): per-row offsets and lengths for rows of different length (N = the longest then)
 static int filtfilt_dev(Engine* e, const double* b, int nb, const double* a, int na, const double* zi, const double* d_x, int R,
-                        int N, double* d_y) {
+                        int N, double* d_y, const FiltRow* rows = nullptr) {
   if (!b || !a || !zi || !d_x || !d_y || nb < 1 || na < 1 || R < 1) return e->fail(PAL_ERR_INVALID, "bad filtfilt arguments");
   const int K = nb > na ? nb : na;
   if (K < 2 || K > 512) return e->fail(PAL_ERR_UNSUPPORTED, "filter length %d outside 2..512", K);
@@ -342,17 +410,22 @@ static int filtfilt_dev(Engine* e, const double* b, int nb, const double* a, int
   for (int q = 0; q < nb; ++q) coef[q] = b[q] / a[0];
   for (int q = 0; q < na; ++q) coef[K + q] = a[q] / a[0];
   for (int q = 0; q < K - 1; ++q) coef[2 * K + q] = zi[q];
-  void *dc = nullptr, *dt = nullptr;
-  PAL_TRY(e->scratch(3, coef.size() * sizeof(double), &dc));
+  void *dc = nullptr, *dt = nullptr, *dd = nullptr;
+  PAL_TRY(e->scratch(3, coef.size() * sizeof(double) + (rows ? size_t(R) * sizeof(FiltRow) : 0), &dc));
   PAL_TRY(e->scratch(1, size_t(R) * (N + 2 * edge) * sizeof(double), &dt));
   PAL_TRY(e->check(hipMemcpyAsync(dc, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, e->stream), "upload"));
-  PAL_TRY(e->check(hipStreamSynchronize(e->stream), "upload sync"));   // `coef` is host memory
+  if (rows) {
+    dd = static_cast<char*>(dc) + coef.size() * sizeof(double);
+    PAL_TRY(e->check(hipMemcpyAsync(dd, rows, size_t(R) * sizeof(FiltRow), hipMemcpyHostToDevice, e->stream), "upload"));
+  }
+  PAL_TRY(e->check(hipStreamSynchronize(e->stream), "upload sync"));   // `coef` / `rows` are host memory
   const double* cb = static_cast<double*>(dc);
   {
     ProfScope ps(e, "k_filtfilt");
     const dim3 grid((R + 63) / 64);
-    if (K == 11) k_filtfilt<11><<<grid, dim3(64), 0, e->stream>>>(d_x, R, N, cb, cb + K, cb + 2 * K, K, static_cast<double*>(dt), d_y);
-    else k_filtfilt<0><<<grid, dim3(64), 0, e->stream>>>(d_x, R, N, cb, cb + K, cb + 2 * K, K, static_cast<double*>(dt), d_y);
+    const FiltRow* dr = static_cast<const FiltRow*>(dd);
+    if (K == 11) k_filtfilt<11><<<grid, dim3(64), 0, e->stream>>>(d_x, R, N, dr, cb, cb + K, cb + 2 * K, K, static_cast<double*>(dt), d_y);
+    else k_filtfilt<0><<<grid, dim3(64), 0, e->stream>>>(d_x, R, N, dr, cb, cb + K, cb + 2 * K, K, static_cast<double*>(dt), d_y);
   }
   return e->check(hipGetLastError(), "k_filtfilt");
 }
@@ -547,6 +620,22 @@ int pal_filtfilt_dev(pal_handle h, const double* b, int nb, const double* a, int
                      int R, int N, double* d_out) {
   ENGINE(h);
   return filtfilt_dev(e, b, nb, a, na, zi, d_rows, R, N, d_out);
+}
+
+int pal_filtfilt_ragged_dev(pal_handle h, const double* b, int nb, const double* a, int na, const double* zi, const double* d_in,
+                            double* d_out, int R, const int64_t* in_off, const int64_t* out_off, const int32_t* lengths) {
+  ENGINE(h);
+  if (!in_off || !out_off || !lengths || R < 1) return e->fail(PAL_ERR_INVALID, "bad filtfilt arguments");
+  const int K = nb > na ? nb : na;
+  std::vector<FiltRow> rows(static_cast<size_t>(R));
+  int nmax = 0;
+  for (int r = 0; r < R; ++r) {
+    if (lengths[r] <= 3 * K) return e->fail(PAL_ERR_INVALID, "The length of the input vector x must be greater than padlen, which is %d.", 3 * K);
+    if (in_off[r] < 0 || out_off[r] < 0) return e->fail(PAL_ERR_INVALID, "negative row offset");
+    rows[size_t(r)] = FiltRow{in_off[r], out_off[r], lengths[r], 0};
+    nmax = lengths[r] > nmax ? lengths[r] : nmax;
+  }
+  return filtfilt_dev(e, b, nb, a, na, zi, d_in, R, nmax, d_out, rows.data());
 }
 
 int pal_wiener3_dev(pal_handle h, const double* d_rows, int R, int N, double* d_out) {

@@ -297,6 +297,18 @@ class Engine:
         self._check(self._lib.pal_filtfilt_dev(self._h, b.ctypes.data, b.shape[0], a.ctypes.data, a.shape[0], zi.ctypes.data,
                                                C.c_void_p(d_rows), int(r), int(n), C.c_void_p(d_out)))
 
+    def filtfilt_ragged_dev(self, b, a, zi, d_in: int, d_out: int, in_off, out_off, lengths) -> None:
+        """Rows of different lengths in one launch: row r = d_in[in_off[r] : + lengths[r]] -> d_out[out_off[r] : ...] (offsets in doubles)."""
+        b, a, zi = f64(b), f64(a), f64(zi)
+        io = np.ascontiguousarray(in_off, dtype=np.int64)
+        oo = np.ascontiguousarray(out_off, dtype=np.int64)
+        ln = np.ascontiguousarray(lengths, dtype=np.int32)
+        if not (io.shape == oo.shape == ln.shape) or io.ndim != 1:
+            raise ValueError("one offset pair and one length per row")
+        self._check(self._lib.pal_filtfilt_ragged_dev(self._h, b.ctypes.data, b.shape[0], a.ctypes.data, a.shape[0], zi.ctypes.data,
+                                                      C.c_void_p(d_in), C.c_void_p(d_out), io.shape[0], io.ctypes.data, oo.ctypes.data,
+                                                      ln.ctypes.data))
+
     def wiener3_dev(self, d_rows: int, r: int, n: int, d_out: int) -> None:
         self._check(self._lib.pal_wiener3_dev(self._h, C.c_void_p(d_rows), int(r), int(n), C.c_void_p(d_out)))
 

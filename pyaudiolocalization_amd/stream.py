@@ -46,54 +46,93 @@ def tdoa_stream(bases: Sequence[np.ndarray], delays: Sequence[np.ndarray], gains
     tables = np.zeros((nf, npairs), dtype=RECORD)
     lengths = np.zeros(nf, dtype=np.int64)
 
-    by_total: Dict[Tuple[int, int], List[int]] = defaultdict(list)          # frames that share the simulation transform
+    def out_len_of(total: int) -> int:
+        return trim_len if 0 < trim_len < total else total
+
+    by_out: Dict[int, List[int]] = defaultdict(list)                       # frames whose simulated rows have one length
     for f in range(nf):
-        by_total[(int(totals[f]), len(bases[f]))].append(f)
-    for (total, nbase), members in by_total.items():
-        out_len = trim_len if 0 < trim_len < total else total
+        by_out[out_len_of(int(totals[f]))].append(f)
+    for out_len, members in by_out.items():
         for at in range(0, len(members), frames_per_batch):
             group = members[at: at + frames_per_batch]
             b = len(group)
-            base = np.ascontiguousarray([bases[f] for f in group], dtype=np.float64)
-            dl = np.ascontiguousarray([delays[f] for f in group], dtype=np.float64)
-            gn = np.ascontiguousarray([gains[f] for f in group], dtype=np.float64)
-            d_base, d_dl, d_gn = eng.alloc(base.nbytes), eng.alloc(dl.nbytes), eng.alloc(gn.nbytes)
             d_sim = eng.alloc(b * m * out_len * 8)
             try:
-                eng.upload(d_base, base); eng.upload(d_dl, dl); eng.upload(d_gn, gn)
-                eng.simulate_multipath_dev(d_base, b, nbase, fs, total, d_dl, d_gn, m, k, trim_len, d_sim)      # main.py:165
+                # ---- simulate (main.py:165): frames that share the transform length 2 * total go through one call
+                by_total: Dict[Tuple[int, int], List[int]] = defaultdict(list)
+                for q, f in enumerate(group):
+                    by_total[(int(totals[f]), len(bases[f]))].append(q)
+                for (total, nbase), local in by_total.items():
+                    base = np.ascontiguousarray([bases[group[q]] for q in local], dtype=np.float64)
+                    dl = np.ascontiguousarray([delays[group[q]] for q in local], dtype=np.float64)
+                    gn = np.ascontiguousarray([gains[group[q]] for q in local], dtype=np.float64)
+                    d_base, d_dl, d_gn = eng.alloc(base.nbytes), eng.alloc(dl.nbytes), eng.alloc(gn.nbytes)
+                    contiguous = local == list(range(local[0], local[0] + len(local)))
+                    d_part = d_sim + local[0] * m * out_len * 8 if contiguous else eng.alloc(len(local) * m * out_len * 8)
+                    try:
+                        eng.upload(d_base, base); eng.upload(d_dl, dl); eng.upload(d_gn, gn)
+                        eng.simulate_multipath_dev(d_base, len(local), nbase, fs, total, d_dl, d_gn, m, k, trim_len, d_part)
+                        if not contiguous:                    # frames of this length are scattered over the batch: move them home
+                            zero = np.zeros(m, dtype=np.int32)
+                            for i, q in enumerate(local):
+                                eng.align_rows_dev(d_part + i * m * out_len * 8, m, out_len, zero, out_len, d_sim + q * m * out_len * 8)
+                        eng.synchronize()
+                    finally:
+                        eng.free(d_base); eng.free(d_dl); eng.free(d_gn)
+                        if not contiguous:
+                            eng.free(d_part)
                 ref, kpk, win, pk, refpk = eng.sync_measure_dev(d_sim, b, m, out_len)                          # utils.py:413-427
                 pads = np.zeros((b, m), dtype=np.int32)
                 for q in range(b):                                                                            # utils.py:428-451
                     shifts = sync_shifts_from_measurements(kpk[q], win[q], pk[q], refpk[q], int(ref[q]), [out_len] * m, out_len, fs)
                     lowest = min(shifts)
                     pads[q] = [max(0, int(round(sh - lowest))) for sh in shifts]
+                # one buffer for the whole batch: the frames of one synchronised length L sit together ([frames][M][L]) so
+                # that each length is one pair-table call, and ALL rows go through the prefilter in ONE launch (one lane
+                # per row: a launch takes as long for 64 rows as for 65 536)
                 by_len: Dict[int, List[int]] = defaultdict(list)
                 for q in range(b):
                     by_len[out_len + int(pads[q].max())].append(q)
-                for length, local in by_len.items():                 # frames of one synchronised length: one pair-table call
-                    nb = len(local)
-                    d_al, d_flt, d_tab = eng.alloc(nb * m * length * 8), eng.alloc(nb * m * length * 8), eng.alloc(nb * npairs * RECORD.itemsize)
-                    try:
-                        contiguous = local == list(range(local[0], local[0] + nb))
-                        if contiguous:
-                            eng.align_rows_dev(d_sim + local[0] * m * out_len * 8, nb * m, out_len, pads[local].reshape(-1), length, d_al)
+                region, at_d = {}, 0
+                for length, local in by_len.items():
+                    region[length] = at_d
+                    at_d += len(local) * m * length
+                d_al, d_flt = eng.alloc(at_d * 8), eng.alloc(at_d * 8)
+                d_tab = eng.alloc(b * npairs * RECORD.itemsize)
+                try:
+                    offs, lens = [], []
+                    for length, local in by_len.items():
+                        base_d = region[length]
+                        nb = len(local)
+                        if local == list(range(local[0], local[0] + nb)):
+                            eng.align_rows_dev(d_sim + local[0] * m * out_len * 8, nb * m, out_len, pads[local].reshape(-1), length,
+                                               d_al + base_d * 8)
                         else:
                             for i, q in enumerate(local):
-                                eng.align_rows_dev(d_sim + q * m * out_len * 8, m, out_len, pads[q], length, d_al + i * m * length * 8)
-                        if design is None:
-                            eng.wiener3_dev(d_al, nb * m, length, d_flt)                                       # main.py:191
-                        else:
-                            eng.filtfilt_dev(design[0], design[1], design[2], d_al, nb * m, length, d_flt)
-                        eng.gcc_phat_all_pairs_dev(d_flt, nb, m, length, prm, d_tab)                           # main.py:202-228
-                        eng.synchronize()
-                        got = np.zeros((nb, npairs), dtype=RECORD)
-                        eng.download(got, d_tab)
+                                eng.align_rows_dev(d_sim + q * m * out_len * 8, m, out_len, pads[q], length,
+                                                   d_al + (base_d + i * m * length) * 8)
+                        offs.extend(base_d + k * length for k in range(nb * m))
+                        lens.extend([length] * (nb * m))
+                    if design is None:                                                                         # main.py:191
+                        for length, local in by_len.items():
+                            eng.wiener3_dev(d_al + region[length] * 8, len(local) * m, length, d_flt + region[length] * 8)
+                    else:
+                        eng.filtfilt_ragged_dev(design[0], design[1], design[2], d_al, d_flt, offs, offs, lens)
+                    row0 = 0
+                    for length, local in by_len.items():                                                       # main.py:202-228
+                        eng.gcc_phat_all_pairs_dev(d_flt + region[length] * 8, len(local), m, length, prm, d_tab + row0 * npairs * RECORD.itemsize)
+                        row0 += len(local)
+                    eng.synchronize()
+                    got = np.zeros((b, npairs), dtype=RECORD)
+                    eng.download(got, d_tab)
+                    row0 = 0
+                    for length, local in by_len.items():
                         for i, q in enumerate(local):
-                            tables[group[q]] = got[i]
+                            tables[group[q]] = got[row0 + i]
                             lengths[group[q]] = length
-                    finally:
-                        eng.free(d_al); eng.free(d_flt); eng.free(d_tab)
+                        row0 += len(local)
+                finally:
+                    eng.free(d_al); eng.free(d_flt); eng.free(d_tab)
             finally:
-                eng.free(d_base); eng.free(d_dl); eng.free(d_gn); eng.free(d_sim)
+                eng.free(d_sim)
     return tables, lengths
