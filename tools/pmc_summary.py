@@ -17,6 +17,8 @@ def bench_name(kernel):
     k = kernel.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("pal::", "")
     k = re.sub(r"k_pfa_rows<(\d+), false>", r"k_pfa_rows<\1>", k)
     k = re.sub(r"k_pfa_cols<[\d, ]+>", "k_pfa_cols", k)
+    k = re.sub(r"k_pfa_cols_stats<[^>]*>", "k_pfa_cols_stats", k)
+    k = re.sub(r"k_peak_finish<(true|false)>", "k_peak_finish", k)
     k = re.sub(r"k_rows<(\d+), true>", r"k_rows<\1,conv>", k)
     k = re.sub(r"k_rows<(\d+), false>", r"k_rows<\1,fwd>", k)
     return k.replace(", ", ",")
@@ -30,6 +32,7 @@ for path in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
             cell[0] += float(row["Counter_Value"])
             cell[1] += 1
 traffic = {}
+flops = {}
 for k in sorted(agg):
     print(k)
     for c in sorted(agg[k]):
@@ -38,6 +41,16 @@ for k in sorted(agg):
     if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
         f, w = agg[k]["FETCH_SIZE"], agg[k]["WRITE_SIZE"]
         traffic[k] = round((2.0 * f[0] / f[1] + w[0] / w[1]) * 1024.0)
+    if "SQ_INSTS_VALU_FMA_F64" in agg[k]:
+        # fp64 operations per dispatch: wave-level instruction counts x 64 lanes, an FMA = 2 (the rocprofv3 expression for
+        # SQ_INSTS_VALU_FLOPS_FP64 without its integer term)
+        g = lambda c: agg[k][c][0] / agg[k][c][1] if c in agg[k] else 0.0
+        flops[k] = round((2 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")
+                          + g("SQ_INSTS_VALU_TRANS_F64")) * 64)
 if out:
     json.dump(traffic, open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out)
+    if flops:
+        fout = out.replace("traffic", "flops") if "traffic" in out else out + ".flops.json"
+        json.dump(flops, open(fout, "w"), indent=1, sort_keys=True)
+        print("wrote", fout)
