@@ -372,13 +372,22 @@ def main() -> None:
             "launches_timed": dom_launches, "event_sampling": f"every {args.event_every}th launch group",
             "pairs_per_launch": round(pairs_per_launch, 2)})
     flops = fp64_flops_per_pair(info, m, length)
+    flops_source = "operation count of the kernels' structure (DESIGN.md section 5), FMA = 2"
+    mpath = os.path.join(ROOT, "profiles", "fp64_flops_per_pair.json")
+    if args.config == "metric" and length == 44100 and m == 64 and os.path.exists(mpath):
+        try:                                                       # measured instruction counts of an earlier PMC pass of this workload
+            rec = json.load(open(mpath))["metric"]
+            flops = float(rec["fp64_flops_per_pair"])
+            flops_source = "measured: fp64 instruction counters of an earlier PMC pass of this command, NOT this run (profiles/fp64_flops_per_pair.json)"
+        except Exception:
+            pass
     roofline_fp64 = None
     if flops:
         tf = value / world * flops / 1e12
         roofline_fp64 = {"bound": "fp64-valu", "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / FP64_PEAK_TFLOPS, 4), "flops_per_pair": round(flops),
                          "peak_source": "v_fma_f64 rate measured on MI355X (tools/mfma_f64_rate.hip); data sheet 78.6",
-                         "flops_source": "operation count of the kernels' structure (DESIGN.md section 5), FMA = 2"}
+                         "flops_source": flops_source}
     binding = None
     if roofline_fp64:
         binding = "fp64-valu" if roofline_fp64["frac"] > roofline["frac"] else "hbm"
