@@ -35,7 +35,7 @@ struct Conv {
 // chirp convolutions of length M = 2^lm that never leave LDS, then dense N1-point DFTs down the columns.
 struct Pfa {
   int n1 = 0, n2 = 0;      // N1 <= 127 (dense), N2 <= M/2 (in-LDS Bluestein)
-  int lm = 0;              // log2 M, 10..12
+  int lm = 0;              // log2 M: 10..12 two tiles per workgroup in LDS (pfa_kernels.h), 13..14 one register-resident tile (pfa_big.h)
   int u1 = 0;              // N2^-1 mod N1
   long long e1 = 0, e2 = 0;   // CRT idempotents: k = (e1 k1 + e2 k2) mod n
   int nch = 1;             // accumulator chunks of the column pass
@@ -87,6 +87,7 @@ struct Engine {
   bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
   bool allow_pfa = true;           // PAL_PFA=0 keeps the PHAT inverse on the four-step chirp convolution
   bool allow_rader = true;         // PAL_RADER=0 keeps the row pass on the in-LDS chirp convolution
+  bool allow_big = true;           // PAL_PFA_BIG=0: no register-resident row tiles (N2 <= 2048 only, as in round 1)
   int pfa_sub = 0;                 // transforms per row/column pass of the prime-factor route (PAL_PFA_SUB; 0 = whole group)
   std::string err;
   int chunk = 128;                              // transforms per launch group (forward spectra, simulation, synchronisation)
@@ -103,8 +104,8 @@ struct Engine {
   std::map<size_t, XConv> xconvs;                    // sequence length -> convolution of pal_xcorr_vs_ref
   int max_plans = 32;                                // PAL_MAX_PLANS: bound of both caches (least recently used out first)
   long long plan_clock = 0;
-  cd* stage_tw[13] = {};                        // stage-major twiddles per log2 N
-  cd* stage_twc[13] = {};                       // the same with a compact last stage (fft_core.h stage_twc_size)
+  cd* stage_tw[16] = {};                        // stage-major twiddles per log2 N (<= 14: the big row tiles of pfa_big.h)
+  cd* stage_twc[16] = {};                       // the same with a compact last stage (fft_core.h stage_twc_size)
   // growable device scratch
   void* ws[16] = {};
   size_t ws_bytes[16] = {};

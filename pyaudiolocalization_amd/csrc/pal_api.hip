@@ -247,6 +247,8 @@ int pal_create(int device, pal_handle* out) {
   if (env) e->allow_pfa = atoi(env) != 0;
   env = getenv("PAL_RADER");
   if (env) e->allow_rader = atoi(env) != 0;
+  env = getenv("PAL_PFA_BIG");
+  if (env) e->allow_big = atoi(env) != 0;
   env = getenv("PAL_PFA_FWD");
   if (env) e->pfa_forward = atoi(env) != 0;
   env = getenv("PAL_FUSED");

@@ -57,8 +57,7 @@ constexpr int kBins = 2048;       // histogram bins (sample pivots, list search,
 constexpr int kSmall = 1024;      // exact rank search capacity
 constexpr int kMemo = 1024;       // resolved peaks remembered per selection
 constexpr int kStack = 64;        // depth of the suppression recursion
-constexpr int kFusedColsOwn = 62; // columns per block of the fused column pass (pfa_cols_stats.h kColsOwn)
-constexpr int kMaxStaged = 40;    // segments whose results the finish launch stages through LDS (the fused column pass has at most ceil(2048 / 62) = 34 blocks)
+constexpr int kMaxStaged = 136;   // segments whose results the finish launch stages through LDS (the fused column pass has at most ceil(8192 / 62) = 133 blocks)
 constexpr int kUnroll = 4;        // 16-byte loads in flight per lane
 constexpr int kTile = kTS * kUnroll;   // element pairs per tile of the stream
 
@@ -899,6 +898,31 @@ __global__ __launch_bounds__(kT, 4) void k_peak_finish(PeakArgs a, pal_pair_reco
     for (int i = tid; i < S * int(sizeof(Partial) / sizeof(double)); i += kT) dst[i] = src[i];
     __syncthreads();
   }
+  if (local && staged && S > 16) {
+    // many column blocks (row lengths N2 up to 8192: 133 of them): one segment per lane, workgroup reductions
+    Partial pt;
+    pt.imax = pt.imin = pt.mb = -1;
+    pt.vmax = pt.hb = 0; pt.vmin = INFINITY; pt.plat = pt.pfloor = -INFINITY;
+    pt.s1 = pt.s2 = pt.a1 = pt.a2 = 0; pt.below = 0;
+    if (tid < S) pt = sparts[tid];
+    vmax = pt.vmax; imax = pt.imax;
+    barg<0>(vmax, imax, s, tid);
+    __syncthreads();
+    hb = pt.hb; mb = pt.mb;
+    barg<2>(hb, mb, s, tid);
+    __syncthreads();
+    vmin = -block_max<kNW>(tid < S && pt.imin >= 0 ? -pt.vmin : -INFINITY, s.red_d, tid);
+    imin = vmin < INFINITY ? 0 : -1;
+    __syncthreads();
+    plat = block_max<kNW>(pt.plat, s.red_d, tid);
+    __syncthreads();
+    pre.pfloor = block_max<kNW>(pt.pfloor, s.red_d, tid);
+    __syncthreads();
+    double sums[4] = {pt.s1, pt.s2, pt.a1, pt.a2};
+    bsum_many<4, kNW>(sums, s.many, tid);
+    s1 = sums[0]; s2 = sums[1]; a1 = sums[2]; a2 = sums[3];
+    __syncthreads();
+  } else
   for (int q = 0; q < S; ++q) {
     const Partial pt = staged ? sparts[q] : a.parts[size_t(row) * S + q];
     plat = fmax(plat, pt.plat);
@@ -960,7 +984,7 @@ __global__ __launch_bounds__(kT, 4) void k_peak_finish(PeakArgs a, pal_pair_reco
       for (int q = 0; q < S && N2 > 0; ++q) {
         const double pf = staged ? sparts[q].pfloor : a.parts[size_t(row) * S + q].pfloor;
         if (!(pf > -INFINITY) || (mb >= 0 && hb >= pf)) continue;          // (uniform)
-        const int c0 = q * kFusedColsOwn, cols = N2 - c0 < kFusedColsOwn ? N2 - c0 : kFusedColsOwn;
+        const int c0 = q * a.cols_per_block, cols = N2 - c0 < a.cols_per_block ? N2 - c0 : a.cols_per_block;
         eh = 0;
         em = -1;
         for (int k = tid; k < cols * N1; k += kT) test(c0 + k % cols + N2 * (k / cols), eh, em);
@@ -1233,6 +1257,7 @@ int Engine::peaks_setup(const double* corr, size_t stride, int rows, int n, int 
   a.snr_w = w > 1 ? w : 1;
   a.edge_n2 = blocks > 0 ? grid_n2 : 0;
   a.local_pivots = blocks > 0 ? 1 : 0;
+  a.cols_per_block = 62;
   a.stamps = nullptr;
   if (blocks > 0) {
     a.splits = blocks;

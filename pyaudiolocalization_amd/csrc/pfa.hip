@@ -31,6 +31,7 @@
 #include "pfa_rader.h"
 #include "pfa_cols_stats.h"
 #include "pfa_forward.h"
+#include "pfa_big.h"
 
 namespace pal {
 
@@ -78,11 +79,13 @@ int Engine::build_pfa(Plan& pl) {
   for (long long d = 1; d <= 127 && d <= n; d += 2) {
     if (n % d) continue;
     const long long r = n / d;
-    if (r > 2048 || gcd_ll(d, r) != 1) continue;
+    if (r > (allow_big ? 8192 : 2048) || gcd_ll(d, r) != 1) continue;
     int lm = 10;
     while ((1ll << lm) < 2 * r - 1) ++lm;
-    const long long cost = ((d + 1) / 2) * (2ll << lm);
-    if (best < 0 || cost < best) { best = cost; bn1 = int(d); bn2 = int(r); blm = lm; }
+    // tile points of the row pass: two tiles per row pair in LDS, or (lm >= 13, pfa_big.h) one register-resident tile per
+    // row, whose stages exchange through LDS twice per boundary: weighted 1.25
+    const long long cost = lm >= 13 ? d * (1ll << lm) * 5 / 4 : ((d + 1) / 2) * (2ll << lm);
+    if (best < 0 || cost < best || (cost == best && lm < blm)) { best = cost; bn1 = int(d); bn2 = int(r); blm = lm; }   // (ties: the smaller tile)
   }
   if (best < 0 || size_t(best) > pl.inv.M() + pl.inv.M() / 2) return PAL_OK;   // the four-step route is no worse
   Pfa f;
@@ -95,7 +98,7 @@ int Engine::build_pfa(Plan& pl) {
   if (u2 & 1) u2 += bn2;                       // even multiplier: the chirp is periodic mod N2 and symmetric
   const int h = (bn1 - 1) / 2;
   f.nch = h > 0 ? (h + kPfaTC - 1) / kPfaTC : 1;
-  const cd* tws = blm >= 11 ? stage_table_compact(blm) : stage_table(blm);
+  const cd* tws = blm >= 13 ? stage_table(blm) : (blm >= 11 ? stage_table_compact(blm) : stage_table(blm));
   if (!tws || !stage_table(blm)) return fail(PAL_ERR_NOMEM, "twiddle tables");   // (the full table feeds the register twiddles)
   PAL_HIP(hipMalloc(&f.b, sizeof(cd) * bn2));
   PAL_HIP(hipMalloc(&f.hhat, sizeof(cd) << blm));
@@ -103,7 +106,9 @@ int Engine::build_pfa(Plan& pl) {
   k_make_chirp<<<dim3((bn2 + 255) / 256), dim3(256), 0, stream>>>(f.b, bn2, int(u2));
   k_make_roots<<<dim3((bn1 + 255) / 256), dim3(256), 0, stream>>>(f.r1, bn1, double(bn1));
   const double scale = 1.0 / (double(1 << blm) * double(n));   // inverse FFT_M and numpy.fft.ifft's 1/n
-  PAL_SWITCH_LM(blm, k_pfa_hhat<LM><<<dim3(1), dim3(PfaLds<LM>::kLanes), 0, stream>>>(f.b, bn2, f.hhat, scale, tws));
+  if (blm == 13) k_pfa_hhat_big<13><<<dim3(1), dim3(BigTile<13>::kLanes), 0, stream>>>(f.b, bn2, f.hhat, scale, tws);
+  else if (blm == 14) k_pfa_hhat_big<14><<<dim3(1), dim3(BigTile<14>::kLanes), 0, stream>>>(f.b, bn2, f.hhat, scale, tws);
+  else PAL_SWITCH_LM(blm, k_pfa_hhat<LM><<<dim3(1), dim3(PfaLds<LM>::kLanes), 0, stream>>>(f.b, bn2, f.hhat, scale, tws));
   PAL_HIP(hipGetLastError());
   // cos / sin of 2 pi j t / N1 with the argument reduced exactly (j t mod N1) before the long-double evaluation
   std::vector<double> tab(size_t(h + kPfaUnr) * f.nch * 2 * kPfaTC, 0.0);   // kPfaUnr zero rows behind the last step
@@ -219,6 +224,15 @@ int Engine::pfa_rows(const Plan& pl, const cd* permuted, const int4* quads, int 
                    f.n1, f.n2, f.rows(), G, 1.0f / float(f.n1), 1.0 / double(pl.n), nullptr};
     k_pfa_rows_rader<11, 9, 10><<<dim3(unsigned(G) * unsigned(f.rows())), dim3(256), 0, on>>>(a);
     PAL_HIP(hipGetLastError());
+  } else if (f.lm >= 13) {
+    char name[48];
+    snprintf(name, sizeof name, "k_pfa_rows_big<%d>", f.lm);
+    ProfScope ps(this, name, on);
+    PfaRowsArgs a{permuted, quads, Y, f.b, f.hhat, f.r1, stage_table(f.lm), stage_table(f.lm), f.rowtab, f.n1, f.n2, f.rows(), G, f.u1, 1.0f / float(f.n1), nullptr};
+    const unsigned grid = unsigned(G) * unsigned(f.n1);        // one workgroup per row of Y
+    if (f.lm == 13) k_pfa_rows_big<13><<<dim3(grid), dim3(BigTile<13>::kLanes), 0, on>>>(a);
+    else k_pfa_rows_big<14><<<dim3(grid), dim3(BigTile<14>::kLanes), 0, on>>>(a);
+    PAL_HIP(hipGetLastError());
   } else {
     char name[48];
     snprintf(name, sizeof name, "k_pfa_rows<%d>", f.lm);
@@ -292,18 +306,25 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
                                  const int* zero_rows, const pal_phat_params& prm, int n2, pal_pair_record* table, int32_t* ksel_multi,
                                  hipStream_t on) {
   const Pfa& f = pl.pfa;
-  const int nblk = (f.n2 + kColsOwn - 1) / kColsOwn;
+  // short column DFTs (one chunk: N1 <= 23): the four wavefronts of a workgroup take four neighbouring strips
+  const bool shortcols = f.nch <= 1;
+  const int per_blk = shortcols ? kColsOwn * 4 : kColsOwn;
+  const int nblk = (f.n2 + per_blk - 1) / per_blk;
   PeakArgs a;
   PAL_TRY(peaks_setup(corr, stride, rows, pl.n, n2, prm, nblk, f.n2, on, a));
+  a.cols_per_block = per_blk;
   PAL_TRY(pfa_rows(pl, permuted, quads, G, Y, on));
   {
     ProfScope ps(this, "k_pfa_cols_stats", on);
-    const dim3 grid(unsigned(G) * unsigned(nblk)), lanes(256);
+    const dim3 grid(unsigned(G) * unsigned(nblk));
     const bool full = (f.n1 - 1) / 2 == f.nch * kPfaTC;          // every chunk index exists (N1 = 89: 44 = 4 x 11)
     const bool adaptive = a.method > 0;
-#define PAL_COLS_STATS(AD, FU) k_pfa_cols_stats<kPfaTC, kPfaUnr, AD, FU><<<grid, lanes, 0, on>>>(Y, corr, stride, f.n1, f.n2, G, f.nch, f.T, zero_rows, a, rows)
-    if (adaptive) { if (full) PAL_COLS_STATS(true, true); else PAL_COLS_STATS(true, false); }
-    else { if (full) PAL_COLS_STATS(false, true); else PAL_COLS_STATS(false, false); }
+    const int nw = f.nch == 2 ? 2 : 4;                         // wavefronts per workgroup = chunks (three chunks: the fourth wavefront idles) or strips
+#define PAL_COLS_STATS(AD, FU, NW, ST) k_pfa_cols_stats<kPfaTC, kPfaUnr, AD, FU, NW, ST><<<grid, dim3(64 * NW), 0, on>>>(Y, corr, stride, f.n1, f.n2, G, f.nch, f.T, zero_rows, a, rows)
+#define PAL_COLS_STATS_NW(AD, FU) do { if (shortcols) PAL_COLS_STATS(AD, false, 4, true); else if (nw == 2) PAL_COLS_STATS(AD, FU, 2, false); else PAL_COLS_STATS(AD, FU, 4, false); } while (0)
+    if (adaptive) { if (full) PAL_COLS_STATS_NW(true, true); else PAL_COLS_STATS_NW(true, false); }
+    else { if (full) PAL_COLS_STATS_NW(false, true); else PAL_COLS_STATS_NW(false, false); }
+#undef PAL_COLS_STATS_NW
 #undef PAL_COLS_STATS
     PAL_HIP(hipGetLastError());
   }

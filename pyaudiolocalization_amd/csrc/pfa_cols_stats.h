@@ -37,7 +37,7 @@
 
 namespace pal {
 
-constexpr int kColsOwn = 62;      // columns a workgroup of the fused column pass owns (64 lanes - two border lanes; peaks.hip kFusedColsOwn)
+constexpr int kColsOwn = 62;      // columns a workgroup of the fused column pass owns (64 lanes - two border lanes)
 
 struct ColsWaveResult {           // one wavefront's share of a row segment
   double vmax, vmin, hb, s1, s2, a1, plat;
@@ -61,8 +61,12 @@ __device__ __forceinline__ double min_raw(double a, double b) {
 
 // ADAPTIVE: threshold method 'adaptive' (mean + std of |corr|: sum |x| instead of the histogram).
 // FULL: every chunk index exists ((N1 - 1) / 2 == nch * TC, e.g. N1 = 89): no per-sample existence tests.
-template <int TC, int UNR, bool ADAPTIVE, bool FULL>
-__global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride, int N1, int N2,
+// NW: wavefronts per workgroup (2 or 4).  STRIPS = false: they are the chunks of output indices of ONE 62-column strip.
+// STRIPS = true (a short column DFT with a single chunk, N1 <= 23, e.g. 47 999 = 7 x 6857): they are NW neighbouring strips,
+// so that the block's histogram and window (fixed costs of a workgroup) are shared by NW x 62 columns instead of being
+// paid for 62 x N1 samples.
+template <int TC, int UNR, bool ADAPTIVE, bool FULL, int NW, bool STRIPS>
+__global__ __launch_bounds__(64 * NW) void k_pfa_cols_stats(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride, int N1, int N2,
                                                         int G, int nch, const double* __restrict__ T, const int* __restrict__ zero_rows, PeakArgs pa,
                                                         int rows) {
   __shared__ unsigned hist[2][kLogBins + 1];                  // + one dump bin for the lanes that own nothing
@@ -72,10 +76,11 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
   __shared__ int medbin[2];                                   // bin of the block's own median per row
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ch = wave;                                        // nch <= 4: one workgroup covers every output index
-  const bool active = ch < nch;
+  const int ch = STRIPS ? 0 : wave;                           // nch <= 4: one workgroup covers every output index
   const int g = blockIdx.x % G, cb = blockIdx.x / G;
-  const int m2 = cb * kColsOwn - 1 + lane;
+  const int strip = STRIPS ? cb * NW + wave : cb;             // 62-column strip of this wavefront
+  const bool active = STRIPS ? strip * kColsOwn < N2 : ch < nch;
+  const int m2 = strip * kColsOwn - 1 + lane;
   const bool live = m2 >= 0 && m2 < N2;
   const bool own = live && lane >= 1 && lane <= kColsOwn;
   const bool inner = own && m2 >= 1 && m2 <= N2 - 2;          // both neighbours are samples of the same output index
@@ -83,9 +88,10 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
   const cd* Yg = Y + size_t(g) * N1 * N2 + m2c;
   const int h = (N1 - 1) / 2;
   constexpr bool want_median = !ADAPTIVE;
+  constexpr int LANES = 64 * NW;
   if (want_median) {                                          // histograms of both rows start empty (the loads below are in flight meanwhile)
     unsigned* hz = &hist[0][0];
-    for (int q = tid; q < 2 * (kLogBins + 1); q += 256) hz[q] = 0;
+    for (int q = tid; q < 2 * (kLogBins + 1); q += LANES) hz[q] = 0;
   }
   double cx[TC], sy[TC], cy[TC], sx[TC];
   double sumx = 0, sumy = 0;
@@ -158,9 +164,9 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
     }
   }
   __syncthreads();
-  // ---- the block's median bin per row (every lane scans 8 bins of both rows), then the window around it is published
+  // ---- the block's median bin per row (every lane scans PER bins of both rows), then the window around it is published
   if (want_median) {
-    constexpr int PER = kLogBins / 256;
+    constexpr int PER = kLogBins / LANES;
     unsigned hv[2][PER], sum[2] = {0, 0};
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
     for (int r = 0; r < 2; ++r) {
       unsigned before = 0;
       cnt[r] = 0;
-      for (int w = 0; w < 4; ++w) { before += w < wave ? wtot[w][r] : 0; cnt[r] += wtot[w][r]; }
+      for (int w = 0; w < NW; ++w) { before += w < wave ? wtot[w][r] : 0; cnt[r] += wtot[w][r]; }
       ex[r] = before + inc[r] - sum[r];                        // samples in the bins under this lane's first bin
       const unsigned mid = cnt[r] >> 1;
       unsigned e = ex[r];
@@ -212,7 +218,9 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
   for (int r = 0; r < 2; ++r) {
     const int row = 2 * g + r;
     if (row >= rows) continue;
-    const double vfloor = fmax(fmax(wmax[0][r], wmax[1][r]), fmax(wmax[2][r], wmax[3][r]));   // the block's exact maximum
+    double vfloor = wmax[0][r];                                // the block's exact maximum
+#pragma unroll
+    for (int w = 1; w < NW; ++w) vfloor = fmax(vfloor, wmax[w][r]);
     const double pfloor = vfloor > 0 ? 0.8 * vfloor : -INFINITY;
     // one bound per lane: samples with both neighbours in their row are tested from 0.8 of the maximum on, the grid's
     // edge columns only for the maximum itself, border lanes never
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
     pt.s1 = pt.s2 = pt.a1 = pt.a2 = 0;
     pt.below = 0;
     pt.pad = 0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const ColsWaveResult x = res[w][r];
       if (x.imax >= 0 && (pt.imax < 0 || x.vmax > pt.vmax || (x.vmax == pt.vmax && x.imax < pt.imax))) { pt.vmax = x.vmax; pt.imax = x.imax; }
       pt.vmin = fmin(pt.vmin, x.vmin);
@@ -276,7 +284,8 @@ __global__ __launch_bounds__(256) void k_pfa_cols_stats(const cd* __restrict__ Y
     }
     pt.a2 = pt.s2;                                              // sum |x|^2 = sum x^2 (both shifts are zero on this path)
     pt.imin = 0;                                                // (the finish launch only asks whether the segment has a minimum)
-    const double bmax = fmax(fmax(wmax[0][r], wmax[1][r]), fmax(wmax[2][r], wmax[3][r]));
+    double bmax = wmax[0][r];
+    for (int w = 1; w < NW; ++w) bmax = fmax(bmax, wmax[w][r]);
     pt.pfloor = bmax > 0 ? 0.8 * bmax : -INFINITY;
     pa.parts[size_t(row) * pa.splits + cb] = pt;
   }
