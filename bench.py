@@ -306,9 +306,16 @@ def main() -> None:
             cal.synchronize()
             cal.profile_end()
             alone = {k: v[0] for k, v in cal.profile_entries().items() if v[1] > 0}
-            alone_avg = {k: v[0] / v[1] for k, v in cal.profile_entries().items() if v[1] > 0}
-            cal_groups = -(-((cb * pairs + 1) // 2) // eng.pair_group_size(length))
-            cal_pairs_per_launch = cb * pairs / cal_groups
+            # per FULL launch: the calibration frames end in a partial launch group, so the plain average per launch would
+            # mix a short launch in; total time / units processed x units of a full launch instead (pair kernels: pairs of a
+            # launch group; forward-spectrum kernels: the 256 frames of a launch of 128 packed transforms)
+            full_pairs = 2 * eng.pair_group_size(length)
+            for k, v in cal.profile_entries().items():
+                if v[1] <= 0:
+                    continue
+                forward = "k_pfa_fwd" in k or "FrameLoader" in k or "SpectrumStorer" in k
+                alone_avg[k] = v[0] / (cb * m) * min(256, cb * m) if forward else v[0] / (cb * pairs) * min(full_pairs, cb * pairs)
+            cal_pairs_per_launch = min(full_pairs, cb * pairs)
         except Exception as exc:                                  # reported, never silent: the ranking falls back to elapsed totals
             print(f"[bench] calibration frame failed ({exc}); ranking kernels by elapsed time", file=sys.stderr)
             alone, alone_avg = {}, {}
@@ -425,6 +432,7 @@ def main() -> None:
             "roofline": roofline, "roofline_fp64": roofline_fp64, "binding_roofline": binding,
             "cpu_baseline": cpu, "parity": parity, "kernels_ms": kernels,
             "kernels_alone_us": {k: round(v * 1e3, 2) for k, v in alone_avg.items()},
+            "kernels_alone_note": "single-stream calibration pass, per full launch (group of 2 x %d pairs; forward kernels per 256 frames)" % chunk,
             "timed_region_s": round(elapsed, 3),
         }
         print(json.dumps(line), flush=True)

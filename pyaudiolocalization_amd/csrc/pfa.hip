@@ -73,8 +73,15 @@ int Engine::build_pfa(Plan& pl) {
   pl.pfa = Pfa();
   const long long n = pl.n;
   if (!allow_pfa || pl.nout != pl.n || n < 3 || (n & 1) == 0) return PAL_OK;
-  // best coprime split: fewest tile points NR * 2M, then the smaller N1
-  long long best = -1;
+  // Best coprime split by a time model fitted to this part (microseconds per packed transform inside a launch group of
+  // 240): a row tile of 2^lm points costs w[lm] - 0.005 / 0.011 / 0.026 for the LDS-resident tiles of
+  // 1024 / 2048 / 4096 points (two per workgroup), 0.058 / 0.224 for the register-resident tiles of 8192 / 16384 (pfa_big.h:
+  // the 16384-point tile runs one workgroup per CU at the 128-register limit) - and the column pass 1.15e-5 n for its
+  // traffic plus 4e-8 N1 n for the dense N1-point DFTs.  The four-step route: 1.34e-5 per point of its convolution for the
+  // first two passes, 1.86e-5 n for the last pass and the statistics launches.  A split that cannot take the fused column
+  // pass (more than four chunks of output indices: N1 > 89) must beat the four-step route by 15 %.
+  static const double kTile[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.005, 0.0113, 0.026, 0.058, 0.224};
+  double best = -1;
   int bn1 = 0, bn2 = 0, blm = 0;
   for (long long d = 1; d <= 127 && d <= n; d += 2) {
     if (n % d) continue;
@@ -82,12 +89,16 @@ int Engine::build_pfa(Plan& pl) {
     if (r > (allow_big ? 8192 : 2048) || gcd_ll(d, r) != 1) continue;
     int lm = 10;
     while ((1ll << lm) < 2 * r - 1) ++lm;
-    // tile points of the row pass: two tiles per row pair in LDS, or (lm >= 13, pfa_big.h) one register-resident tile per
-    // row, whose stages exchange through LDS twice per boundary: weighted 1.25
-    const long long cost = lm >= 13 ? d * (1ll << lm) * 5 / 4 : ((d + 1) / 2) * (2ll << lm);
-    if (best < 0 || cost < best || (cost == best && lm < blm)) { best = cost; bn1 = int(d); bn2 = int(r); blm = lm; }   // (ties: the smaller tile)
+    const int chunks = d > 1 ? int(((d - 1) / 2 + kPfaTC - 1) / kPfaTC) : 1;
+    double cost = double(d) * kTile[lm] + double(n) * (1.15e-5 + 4e-8 * double(d));
+    if (chunks > 4) cost *= 1.15;
+    if (best < 0 || cost < best) { best = cost; bn1 = int(d); bn2 = int(r); blm = lm; }
   }
-  if (best < 0 || size_t(best) > pl.inv.M() + pl.inv.M() / 2) return PAL_OK;   // the four-step route is no worse
+  const double four_step = 1.34e-5 * double(pl.inv.M()) + 1.86e-5 * double(n);
+  if (best < 0 || best > four_step) return PAL_OK;             // the four-step route is no worse
+  // (short transforms are launch-bound, the model does not apply: there the split must also stay within 1.5 x the
+  //  four-step route's points, round 1's rule)
+  if (n < 16384 && size_t(((bn1 + 1) / 2) * (2ll << blm)) > pl.inv.M() + pl.inv.M() / 2) return PAL_OK;
   Pfa f;
   f.n1 = bn1; f.n2 = bn2; f.lm = blm;
   f.u1 = int(inv_mod(bn2, bn1));
