@@ -69,6 +69,15 @@ def fp64_flops_per_pair(info: dict, mics: int, length: int):
         per_transform = whiten + rader + epilogue + cols        # one packed transform = two pairs
         forward = per_transform * (mics / 2.0) / pairs          # forward spectra through the same cut, amortised
         return (per_transform / 2.0) + forward + stats
+    if n1:                                                      # prime-factor cut with chirp-convolution row tiles of `tile` points
+        nr, h = (n1 + 1) // 2, (n1 - 1) // 2
+        tiles = n1 if tile >= 8192 else 2 * nr                  # one register tile per row, or two LDS tiles per row pair
+        conv = 2 * 5.0 * tile * np.log2(tile) + 6.0 * tile      # forward FFT, product with the chirp spectrum, inverse FFT
+        whiten = 66.0 * n2 * (n1 if tile >= 8192 else nr)
+        cols = n2 * (h * (6 + 8 * h) + 8 * h) if h else 0.0
+        per_transform = tiles * conv + whiten + 12.0 * n + cols
+        forward = (2 * 5.0 * info["conv_len"] * np.log2(info["conv_len"])) * mics / pairs     # forward spectra: four-step
+        return per_transform / 2.0 + forward + stats
     if not n1:                                                  # four-step chirp convolution: 5 M log2 M per FFT, two FFTs + products
         m = info["conv_len"]
         fft = 5.0 * m * np.log2(m)

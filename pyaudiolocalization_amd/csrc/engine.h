@@ -87,6 +87,7 @@ struct Engine {
   bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
   bool allow_pfa = true;           // PAL_PFA=0 keeps the PHAT inverse on the four-step chirp convolution
   bool allow_rader = true;         // PAL_RADER=0 keeps the row pass on the in-LDS chirp convolution
+  bool xcd_rows = true;            // PAL_XCD_ROWS=0: row passes in plain workgroup order (pfa_kernels.h: row_work_item)
   bool allow_big = true;           // PAL_PFA_BIG=0: no register-resident row tiles (N2 <= 2048 only, as in round 1)
   int pfa_sub = 0;                 // transforms per row/column pass of the prime-factor route (PAL_PFA_SUB; 0 = whole group)
   std::string err;

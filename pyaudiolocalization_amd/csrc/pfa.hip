@@ -35,6 +35,15 @@
 
 namespace pal {
 
+// points per lane of the register-resident row tiles (pfa_big.h); the build can override them for A/B runs
+#ifndef PAL_BIG13_PTS
+#define PAL_BIG13_PTS 32
+#endif
+#ifndef PAL_BIG14_PTS
+#define PAL_BIG14_PTS 32
+#endif
+constexpr int kBig13 = PAL_BIG13_PTS, kBig14 = PAL_BIG14_PTS;
+
 // ------------------------------------------------------------------ plan
 static long long inv_mod(long long a, long long m) {   // a^-1 mod m (gcd = 1), 0 when m == 1
   if (m == 1) return 0;
@@ -75,12 +84,12 @@ int Engine::build_pfa(Plan& pl) {
   if (!allow_pfa || pl.nout != pl.n || n < 3 || (n & 1) == 0) return PAL_OK;
   // Best coprime split by a time model fitted to this part (microseconds per packed transform inside a launch group of
   // 240): a row tile of 2^lm points costs w[lm] - 0.005 / 0.011 / 0.026 for the LDS-resident tiles of
-  // 1024 / 2048 / 4096 points (two per workgroup), 0.058 / 0.224 for the register-resident tiles of 8192 / 16384 (pfa_big.h:
-  // the 16384-point tile runs one workgroup per CU at the 128-register limit) - and the column pass 1.15e-5 n for its
-  // traffic plus 4e-8 N1 n for the dense N1-point DFTs.  The four-step route: 1.34e-5 per point of its convolution for the
-  // first two passes, 1.86e-5 n for the last pass and the statistics launches.  A split that cannot take the fused column
+  // 1024 / 2048 / 4096 points (two per workgroup), 0.050 / 0.145 for the register-resident tiles of 8192 / 16384 (pfa_big.h:
+  // the 16384-point tile runs one workgroup per CU) - and the column pass 1.15e-5 n for its
+  // traffic plus 4e-8 N1 n for the dense N1-point DFTs.  The four-step route: 1.6e-5 per point of its convolution for the
+  // first two passes, 2.2e-5 n for the last pass and the statistics launches.  A split that cannot take the fused column
   // pass (more than four chunks of output indices: N1 > 89) must beat the four-step route by 15 %.
-  static const double kTile[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.005, 0.0113, 0.026, 0.058, 0.224};
+  static const double kTile[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.005, 0.0113, 0.026, 0.050, 0.145};
   double best = -1;
   int bn1 = 0, bn2 = 0, blm = 0;
   for (long long d = 1; d <= 127 && d <= n; d += 2) {
@@ -94,7 +103,7 @@ int Engine::build_pfa(Plan& pl) {
     if (chunks > 4) cost *= 1.15;
     if (best < 0 || cost < best) { best = cost; bn1 = int(d); bn2 = int(r); blm = lm; }
   }
-  const double four_step = 1.34e-5 * double(pl.inv.M()) + 1.86e-5 * double(n);
+  const double four_step = 1.6e-5 * double(pl.inv.M()) + 2.2e-5 * double(n);
   if (best < 0 || best > four_step) return PAL_OK;             // the four-step route is no worse
   // (short transforms are launch-bound, the model does not apply: there the split must also stay within 1.5 x the
   //  four-step route's points, round 1's rule)
@@ -117,8 +126,8 @@ int Engine::build_pfa(Plan& pl) {
   k_make_chirp<<<dim3((bn2 + 255) / 256), dim3(256), 0, stream>>>(f.b, bn2, int(u2));
   k_make_roots<<<dim3((bn1 + 255) / 256), dim3(256), 0, stream>>>(f.r1, bn1, double(bn1));
   const double scale = 1.0 / (double(1 << blm) * double(n));   // inverse FFT_M and numpy.fft.ifft's 1/n
-  if (blm == 13) k_pfa_hhat_big<13><<<dim3(1), dim3(BigTile<13>::kLanes), 0, stream>>>(f.b, bn2, f.hhat, scale, tws);
-  else if (blm == 14) k_pfa_hhat_big<14><<<dim3(1), dim3(BigTile<14>::kLanes), 0, stream>>>(f.b, bn2, f.hhat, scale, tws);
+  if (blm == 13) k_pfa_hhat_big<13, kBig13><<<dim3(1), dim3(BigTile<13, kBig13>::kLanes), 0, stream>>>(f.b, bn2, f.hhat, scale, tws);
+  else if (blm == 14) k_pfa_hhat_big<14, kBig14><<<dim3(1), dim3(BigTile<14, kBig14>::kLanes), 0, stream>>>(f.b, bn2, f.hhat, scale, tws);
   else PAL_SWITCH_LM(blm, k_pfa_hhat<LM><<<dim3(1), dim3(PfaLds<LM>::kLanes), 0, stream>>>(f.b, bn2, f.hhat, scale, tws));
   PAL_HIP(hipGetLastError());
   // cos / sin of 2 pi j t / N1 with the argument reduced exactly (j t mod N1) before the long-double evaluation
@@ -232,24 +241,24 @@ int Engine::pfa_rows(const Plan& pl, const cd* permuted, const int4* quads, int 
   if (f.rader) {
     ProfScope ps(this, "k_pfa_rows_rader<11,9,10>", on);
     PfaRaderArgs a{permuted, quads, Y, f.rd_bhat, f.r1, f.rd_ridx, f.rowtab,
-                   f.n1, f.n2, f.rows(), G, 1.0f / float(f.n1), 1.0 / double(pl.n), nullptr};
-    k_pfa_rows_rader<11, 9, 10><<<dim3(unsigned(G) * unsigned(f.rows())), dim3(256), 0, on>>>(a);
+                   f.n1, f.n2, f.rows(), G, 1.0f / float(f.n1), 1.0 / double(pl.n), nullptr, xcd_rows};
+    k_pfa_rows_rader<11, 9, 10><<<dim3(row_work_grid(G, f.rows(), xcd_rows)), dim3(256), 0, on>>>(a);
     PAL_HIP(hipGetLastError());
   } else if (f.lm >= 13) {
     char name[48];
     snprintf(name, sizeof name, "k_pfa_rows_big<%d>", f.lm);
     ProfScope ps(this, name, on);
-    PfaRowsArgs a{permuted, quads, Y, f.b, f.hhat, f.r1, stage_table(f.lm), stage_table(f.lm), f.rowtab, f.n1, f.n2, f.rows(), G, f.u1, 1.0f / float(f.n1), nullptr};
-    const unsigned grid = unsigned(G) * unsigned(f.n1);        // one workgroup per row of Y
-    if (f.lm == 13) k_pfa_rows_big<13><<<dim3(grid), dim3(BigTile<13>::kLanes), 0, on>>>(a);
-    else k_pfa_rows_big<14><<<dim3(grid), dim3(BigTile<14>::kLanes), 0, on>>>(a);
+    PfaRowsArgs a{permuted, quads, Y, f.b, f.hhat, f.r1, stage_table(f.lm), stage_table(f.lm), f.rowtab, f.n1, f.n2, f.rows(), G, f.u1, 1.0f / float(f.n1), nullptr, xcd_rows};
+    const unsigned grid = row_work_grid(G, f.n1, xcd_rows);    // one workgroup per row of Y
+    if (f.lm == 13) k_pfa_rows_big<13, kBig13><<<dim3(grid), dim3(BigTile<13, kBig13>::kLanes), 0, on>>>(a);
+    else k_pfa_rows_big<14, kBig14><<<dim3(grid), dim3(BigTile<14, kBig14>::kLanes), 0, on>>>(a);
     PAL_HIP(hipGetLastError());
   } else {
     char name[48];
     snprintf(name, sizeof name, "k_pfa_rows<%d>", f.lm);
     ProfScope ps(this, name, on);
-    PfaRowsArgs a{permuted, quads, Y, f.b, f.hhat, f.r1, tws, stage_table(f.lm), f.rowtab, f.n1, f.n2, f.rows(), G, f.u1, 1.0f / float(f.n1), nullptr};
-    const unsigned grid = unsigned(G) * unsigned(f.rows());
+    PfaRowsArgs a{permuted, quads, Y, f.b, f.hhat, f.r1, tws, stage_table(f.lm), f.rowtab, f.n1, f.n2, f.rows(), G, f.u1, 1.0f / float(f.n1), nullptr, xcd_rows};
+    const unsigned grid = row_work_grid(G, f.rows(), xcd_rows);
     PAL_SWITCH_LM(f.lm, k_pfa_rows<LM><<<dim3(grid), dim3(PfaLds<LM>::kLanes), 0, on>>>(a));
     PAL_HIP(hipGetLastError());
   }

@@ -5,14 +5,18 @@
 // most of the lengths the synchronisation padding produces (utils.py:448-456): any n with an odd divisor N1 <= 127 whose
 // cofactor stays under 8192.  A 16 384-point tile is 256 KB as complex doubles, more than a CU's 160 KB of LDS, so here
 //
-//   - the tile lives in REGISTERS: one workgroup of M / 16 lanes (1024 at 16 384 points), 16 points per lane, one
-//     workgroup per row of Y (the two rows k1 / N1 - k1 that share their whitened bins are two workgroups: the
-//     whitening is done twice, 8 % of the arithmetic, for half the registers);
+//   - the tile lives in REGISTERS: one workgroup of M / 32 lanes holding 32 points per lane - 256 lanes at 8192 points (two
+//     workgroups per CU, their phases overlap), 512 lanes at 16 384 (one per CU); either way two wavefronts per SIMD and up
+//     to 256 registers per lane.  (Round 2's first version held 16 points per lane: 1024 lanes at 16 384 points, pinned to
+//     128 registers by its 16 wavefronts, 268 B of spills per lane - 441 us per launch of 240 x 7 rows against 322 now; the
+//     8192-point tile measured 500 us per 240 x 23 rows with 16 points x 512 lanes, 435 with 32 x 256.)  One workgroup per row of Y (the two rows k1 / N1 - k1 that share their whitened bins
+//     are two workgroups: the whitening is done twice, 8 % of the arithmetic, for half the registers);
 //   - LDS only carries the exchange between two Stockham stages, one PLANE at a time: real parts out, barrier, real
-//     parts in, barrier, then the imaginary parts - M doubles (128 KB at 16 384 points, one workgroup per CU; 64 KB and
-//     two per CU at 8192);
-//   - the last forward stage leaves lane `tid` with the bins tid + LANES s, which are exactly the inputs of its first
-//     inverse butterfly: the product with the chirp spectrum needs no exchange.
+//     parts in, barrier, then the imaginary parts - M doubles (128 KB at 16 384 points, 64 KB at 8192);
+//   - a stage of radix R runs PTS / R butterflies per lane (work items tid + LANES q); register q R + r holds input
+//     r of butterfly q, i.e. element tid + LANES (q + (PTS / R) r).  The last forward stage therefore leaves lane `tid`
+//     with the bins tid + LANES s, the same set its first inverse butterflies read: the product with the chirp
+//     spectrum needs no exchange, only a renaming of registers.
 //
 // Same transform as k_pfa_rows otherwise: x[e] = (R^p + i R^q)[k1, e] b[e] (or the conjugate combination of the
 // reversed row for N1 - k1), circular convolution with the chirp kernel through FFT_M, chirp and column twiddle on the
@@ -21,21 +25,32 @@
 #include "conv_kernels.h"
 #include "pfa_kernels.h"
 
+#ifndef PAL_BIG13_TWO_WG
+#define PAL_BIG13_TWO_WG 1
+#endif
+
 namespace pal {
 
-template <int LM> struct BigTile {
-  static constexpr int kM = 1 << LM, kLanes = kM / 16;
+template <int LM, int PTS> struct BigTile {
+  static_assert(PTS == 16 || PTS == 32, "points per lane");
+  static constexpr int kM = 1 << LM, kLanes = kM / PTS, kPts = PTS;
   // LDS position of element e of the plane: the low four bits are XOR-ed with the next four, which spreads the
   // stride-16 stores of the first stage over the banks (a ds_write_b64 conflicts inside groups of 16 lanes only) and
   // keeps 16 consecutive elements a permutation of 16 consecutive slots for the coalesced sides
   __device__ static __forceinline__ int pos(int e) { return e ^ ((e >> 4) & 15); }
+  // register that holds element tid + LANES s before a stage of radix R / after the last stage of radix R
+  __device__ static __forceinline__ constexpr int reg_of(int s, int R) { return (s % (PTS / R)) * R + s / (PTS / R); }
+  __device__ static __forceinline__ constexpr int slot_of(int reg, int R) { return reg / R + (PTS / R) * (reg % R); }
+  static constexpr int kR0 = stage_radix(LM, 0), kRL = stage_radix(LM, stage_tw_last(LM));
+  // wavefronts per SIMD the register allocation must leave room for: two workgroups per CU where their LDS planes fit
+  static constexpr int kWaves = (LM == 13 && PAL_BIG13_TWO_WG) ? 2 * (kLanes / 64) / 4 : 1;
 };
 
-// one stage on the 16 registers of a lane: PER = 16 / R butterflies (work items tid + LANES q), twiddles from the
+// one stage on the PTS registers of a lane: PER = PTS / R butterflies (work items tid + LANES q), twiddles from the
 // stage-major table in global memory (L2-resident: 16 B x 2^LM)
-template <int LM, bool INV, int LP>
+template <int LM, int PTS, bool INV, int LP>
 __device__ __forceinline__ void big_stage(cd* v, const cd* __restrict__ tws, int tid) {
-  constexpr int R = stage_radix(LM, LP), P = 1 << LP, LANES = BigTile<LM>::kLanes, PER = 16 / R;
+  constexpr int R = stage_radix(LM, LP), P = 1 << LP, LANES = BigTile<LM, PTS>::kLanes, PER = PTS / R;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     if constexpr (P > 1) {
@@ -53,11 +68,12 @@ __device__ __forceinline__ void big_stage(cd* v, const cd* __restrict__ tws, int
 
 // exchange between the stage at LP (outputs at their autosort positions) and the next one (inputs i + r NB), one plane
 // at a time through `plane` (M doubles)
-template <int LM, int LP>
+template <int LM, int PTS, int LP>
 __device__ __forceinline__ void big_exchange(double* plane, cd* v, int tid) {
-  constexpr int M = 1 << LM, LANES = BigTile<LM>::kLanes;
-  constexpr int R = stage_radix(LM, LP), P = 1 << LP, PER = 16 / R;
-  constexpr int LP2 = LP + stage_log2r(LM, LP), R2 = stage_radix(LM, LP2), PER2 = 16 / R2, NB2 = M / R2;
+  using B = BigTile<LM, PTS>;
+  constexpr int M = 1 << LM, LANES = B::kLanes;
+  constexpr int R = stage_radix(LM, LP), P = 1 << LP, PER = PTS / R;
+  constexpr int LP2 = LP + stage_log2r(LM, LP), R2 = stage_radix(LM, LP2), PER2 = PTS / R2, NB2 = M / R2;
   int wpos[PER], rpos[PER2];
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
@@ -66,76 +82,74 @@ __device__ __forceinline__ void big_exchange(double* plane, cd* v, int tid) {
   }
 #pragma unroll
   for (int q = 0; q < PER2; ++q) rpos[q] = tid + LANES * q;
-  double xs[16];
+  double xs[PTS];
 #pragma unroll
   for (int q = 0; q < PER; ++q)
 #pragma unroll
-    for (int r = 0; r < R; ++r) plane[BigTile<LM>::pos(wpos[q] + r * P)] = v[q * R + r].x;
+    for (int r = 0; r < R; ++r) plane[B::pos(wpos[q] + r * P)] = v[q * R + r].x;
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < PER2; ++q)
 #pragma unroll
-    for (int r = 0; r < R2; ++r) xs[q * R2 + r] = plane[BigTile<LM>::pos(rpos[q] + r * NB2)];
+    for (int r = 0; r < R2; ++r) xs[q * R2 + r] = plane[B::pos(rpos[q] + r * NB2)];
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < PER; ++q)
 #pragma unroll
-    for (int r = 0; r < R; ++r) plane[BigTile<LM>::pos(wpos[q] + r * P)] = v[q * R + r].y;
+    for (int r = 0; r < R; ++r) plane[B::pos(wpos[q] + r * P)] = v[q * R + r].y;
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < PER2; ++q)
 #pragma unroll
-    for (int r = 0; r < R2; ++r) v[q * R2 + r] = mk(xs[q * R2 + r], plane[BigTile<LM>::pos(rpos[q] + r * NB2)]);
+    for (int r = 0; r < R2; ++r) v[q * R2 + r] = mk(xs[q * R2 + r], plane[B::pos(rpos[q] + r * NB2)]);
   __syncthreads();
 }
 
-template <int LM, bool INV, int LP>
+template <int LM, int PTS, bool INV, int LP>
 __device__ __forceinline__ void big_fft_from(double* plane, const cd* __restrict__ tws, cd* v, int tid) {
-  big_stage<LM, INV, LP>(v, tws, tid);
+  big_stage<LM, PTS, INV, LP>(v, tws, tid);
   if constexpr (!stage_is_last(LM, LP)) {
-    big_exchange<LM, LP>(plane, v, tid);
-    big_fft_from<LM, INV, LP + stage_log2r(LM, LP)>(plane, tws, v, tid);
+    big_exchange<LM, PTS, LP>(plane, v, tid);
+    big_fft_from<LM, PTS, INV, LP + stage_log2r(LM, LP)>(plane, tws, v, tid);
   }
 }
 
-// FFT_M of the 16 registers of every lane.  In: v[r] = element tid + LANES r (first-stage butterfly of a radix-16 first
-// stage).  Out: the last stage's outputs; with RL = its radix and PER = 16 / RL, register q RL + r holds element
-// tid + LANES (q + PER r) - the same SET of elements the lane started with.
-template <int LM, bool INV>
+// FFT_M of the PTS registers of every lane.  In: register BigTile::reg_of(s, kR0) = element tid + LANES s.  Out: register
+// `reg` holds element tid + LANES BigTile::slot_of(reg, kRL) - the same SET of elements the lane started with.
+template <int LM, int PTS, bool INV>
 __device__ __forceinline__ void big_fft(double* plane, const cd* __restrict__ tws, cd* v, int tid) {
   static_assert(stage_radix(LM, 0) == 16, "radix-16 first stage");
-  big_fft_from<LM, INV, 0>(plane, tws, v, tid);
-}
-template <int LM> __device__ __forceinline__ constexpr int big_out_slot(int reg) {   // s of element tid + LANES s held by register `reg` after big_fft
-  constexpr int RL = stage_radix(LM, stage_tw_last(LM)), PER = 16 / RL;
-  return reg / RL + PER * (reg % RL);
+  big_fft_from<LM, PTS, INV, 0>(plane, tws, v, tid);
 }
 
 // chirp spectrum: hhat[e] = scale * FFT_M(h)[e], h[d mod M] = conj(b[|d|]) for |d| < N2 (PfaChirpIn)
-template <int LM>
-__global__ __launch_bounds__(BigTile<LM>::kLanes) void k_pfa_hhat_big(const cd* __restrict__ b, int N2, cd* __restrict__ hhat, double scale,
-                                                                      const cd* __restrict__ tws) {
-  constexpr int M = 1 << LM, LANES = BigTile<LM>::kLanes;
+template <int LM, int PTS>
+__global__ __launch_bounds__((BigTile<LM, PTS>::kLanes)) void k_pfa_hhat_big(const cd* __restrict__ b, int N2, cd* __restrict__ hhat, double scale,
+                                                                           const cd* __restrict__ tws) {
+  using B = BigTile<LM, PTS>;
+  constexpr int M = 1 << LM, LANES = B::kLanes;
   __shared__ double plane[M];
   const int tid = threadIdx.x;
-  cd v[16];
+  cd v[PTS];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e = tid + LANES * r;
-    v[r] = e < N2 ? cconj(b[e]) : (M - e < N2 ? cconj(b[M - e]) : mk(0, 0));
+  for (int s = 0; s < PTS; ++s) {
+    const int e = tid + LANES * s;
+    v[B::reg_of(s, B::kR0)] = e < N2 ? cconj(b[e]) : (M - e < N2 ? cconj(b[M - e]) : mk(0, 0));
   }
-  big_fft<LM, false>(plane, tws, v, tid);
+  big_fft<LM, PTS, false>(plane, tws, v, tid);
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) hhat[tid + LANES * big_out_slot<LM>(reg)] = cscale(v[reg], scale);
+  for (int reg = 0; reg < PTS; ++reg) hhat[tid + LANES * B::slot_of(reg, B::kRL)] = cscale(v[reg], scale);
 }
 
-// grid = G * N1 workgroups (transform fastest), one per row of Y
-template <int LM>
-__global__ __launch_bounds__(BigTile<LM>::kLanes) void k_pfa_rows_big(PfaRowsArgs a) {
-  constexpr int M = 1 << LM, LANES = BigTile<LM>::kLanes;
+// grid = G * N1 workgroups (row_work_item: transform fastest), one per row of Y
+template <int LM, int PTS>
+__global__ __launch_bounds__((BigTile<LM, PTS>::kLanes)) __attribute__((amdgpu_waves_per_eu(BigTile<LM, PTS>::kWaves))) void k_pfa_rows_big(PfaRowsArgs a) {
+  using B = BigTile<LM, PTS>;
+  constexpr int M = 1 << LM, LANES = B::kLanes, HALF = PTS / 2;
   __shared__ double plane[M];
   const int tid = threadIdx.x;
-  const int g = blockIdx.x % a.G, row = blockIdx.x / a.G;
+  int g, row;
+  if (!row_work_item(blockIdx.x, a.G, a.N1, a.xcd, g, row)) return;
   const int N1 = a.N1, N2 = a.N2;
   const bool rev = 2 * row > N1 - 1;                          // rows above (N1-1)/2: the reversed conjugate combination of row N1 - row
   const int k1 = rev ? N1 - row : row;
@@ -148,41 +162,51 @@ __global__ __launch_bounds__(BigTile<LM>::kLanes) void k_pfa_rows_big(PfaRowsArg
   const cd* sc = second ? a.SP + size_t(q.z) * mic + off : sa;   // branch-free loads: a missing second pair re-reads the first one
   const cd* sd = second ? a.SP + size_t(q.w) * mic + off : sb;
   const double keep2 = second ? 1.0 : 0.0;
-  // ---- inputs: the whitened pair bins times the chirp; elements beyond N2 <= M / 2 are zero padding (r >= 8 always)
-  cd v[16];
+  // ---- inputs: the whitened pair bins times the chirp; elements beyond N2 <= M / 2 are zero padding (slots >= PTS / 2 always)
+  cd v[PTS];
 #pragma unroll
-  for (int r0 = 0; r0 < 8; r0 += 2) {                         // two elements at a time: eight spectrum loads in flight
+  for (int s0 = 0; s0 < HALF; s0 += 2) {                      // two elements at a time: eight spectrum loads in flight
     cd va[2], vb[2], vc[2], vd[2], ch[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int e = tid + LANES * (r0 + u), ee = e < N2 ? e : N2 - 1;
+      const int e = tid + LANES * (s0 + u), ee = e < N2 ? e : N2 - 1;
       va[u] = sa[ee]; vb[u] = sb[ee]; vc[u] = sc[ee]; vd[u] = sd[ee];
       ch[u] = a.b[ee];
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int e = tid + LANES * (r0 + u);
+      const int e = tid + LANES * (s0 + u);
       const cd r1 = whiten(va[u], vb[u]);
       const cd r2 = cscale(whiten(vc[u], vd[u]), keep2);
       const cd x = rev ? mk(r1.x + r2.y, r2.x - r1.y) : mk(r1.x - r2.y, r1.y + r2.x);   // conj(R^p) + i conj(R^q), or R^p + i R^q
-      v[r0 + u] = e < N2 ? cmul(x, ch[u]) : mk(0, 0);
+      v[B::reg_of(s0 + u, B::kR0)] = e < N2 ? cmul(x, ch[u]) : mk(0, 0);
     }
+    if constexpr (PTS > 16) asm volatile("" ::: "memory");    // (keeps the next round's loads below: all 80 in flight would not fit the registers)
   }
 #pragma unroll
-  for (int r = 8; r < 16; ++r) v[r] = mk(0, 0);
-  big_fft<LM, false>(plane, a.twfull, v, tid);
-  // ---- product with the chirp spectrum: the lane holds bins tid + LANES s, the inputs of its first inverse butterfly
+  for (int s = HALF; s < PTS; ++s) v[B::reg_of(s, B::kR0)] = mk(0, 0);
+  big_fft<LM, PTS, false>(plane, a.twfull, v, tid);
+  // ---- product with the chirp spectrum: the lane holds bins tid + LANES s, the inputs of its first inverse butterflies
   {
-    cd u[16];
+    cd u[PTS];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int s = big_out_slot<LM>(reg);
-      u[s] = cmul(v[reg], a.hhat[tid + LANES * s]);
+    for (int reg = 0; reg < PTS; ++reg) {
+      if constexpr (PTS > 16) { if (reg % 8 == 0) asm volatile("" ::: "memory"); }   // eight chirp-spectrum loads in flight, not all 32
+      const int s = B::slot_of(reg, B::kRL);
+      u[B::reg_of(s, B::kR0)] = cmul(v[reg], a.hhat[tid + LANES * s]);
     }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) v[s] = u[s];
+    for (int r = 0; r < PTS; ++r) v[r] = u[r];
   }
-  big_fft<LM, true>(plane, a.twfull, v, tid);
+  {
+    // The inverse stages use the same twiddles and the same LDS positions as the forward ones.  Seen through the same
+    // values the compiler keeps all of them live from the forward transform on - about a hundred registers, spilled to
+    // scratch; opaque copies of the table offset and of the lane index make it load / compute them again instead.
+    size_t again = 0;
+    int tid2 = tid;
+    asm volatile("" : "+s"(again), "+v"(tid2));
+    big_fft<LM, PTS, true>(plane, a.twfull + again, v, tid2);
+  }
   // ---- outputs e = tid + LANES s < N2: chirp, column twiddle exp(2 pi i u1 row m2 / N1), Y[row][m2] with m2 = e, or
   //      -e mod N2 for the reversed rows
   if (rev && k1 == 0) return;                                  // (never: row 0 is not reversed)
@@ -190,10 +214,11 @@ __global__ __launch_bounds__(BigTile<LM>::kLanes) void k_pfa_rows_big(PfaRowsArg
   const auto* rt = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.rowtab)) + 2 * row;
   const unsigned uk = unsigned(rt[0]), n1 = unsigned(N1);
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int s = big_out_slot<LM>(reg);
+  for (int reg = 0; reg < PTS; ++reg) {
+    if constexpr (PTS > 16) { if (reg % 8 == 0) asm volatile("" ::: "memory"); }
+    const int s = B::slot_of(reg, B::kRL);
     const int e = tid + LANES * s;
-    if (s < 8 && e < N2) {                                     // (N2 <= M / 2: slots 8 .. 15 are never below N2)
+    if (s < HALF && e < N2) {                                  // (N2 <= M / 2: the upper slots are never below N2)
       const int m2 = rev ? (e ? N2 - e : 0) : e;
       const unsigned x = uk * unsigned(m2);                   // < 127 * 8192 < 2^24: exact in float
       unsigned idx = x - unsigned(float(x) * a.inv) * n1;     // x mod N1, off by at most one N1 either way

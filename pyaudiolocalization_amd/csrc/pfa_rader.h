@@ -36,6 +36,7 @@ struct PfaRaderArgs {
   float inv;             // 1 / N1
   double scale;          // 1 / n: the x[0] and sum terms bypass the scaled convolution
   unsigned long long* stamps;   // diagnostics only (tools/microbench_pfa): 100 MHz clock reads of lane 0 per phase
+  int xcd;               // 1: XCD-aware order of the workgroups (row_work_item, pfa_kernels.h)
 };
 
 // Stages 2-5 of the cyclic convolution on two L-point tiles in LDS (the first stage, along axis R1, has filled them):
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   __shared__ cd total[2];              // sum of the tile-0 / tile-1 inputs (from the convolution's spectrum)
   __shared__ cd dc[2];                 // x[0] of both tiles
   const int tid = threadIdx.x;
-  const int g = blockIdx.x % a.G, k1 = blockIdx.x / a.G;
+  int g, k1;
+  if (!row_work_item(blockIdx.x, a.G, a.NR, a.xcd, g, k1)) return;
   const int N1 = a.N1, N2 = a.N2;
   const PlainTile tile{data, L};
   unsigned long long* const stamps = a.stamps;
