@@ -19,18 +19,30 @@ import numpy as np
 from ._ffi import RECORD
 from .engine import Engine, default_engine, make_params
 from .signal_processing import _filter_design
-from .utils import sync_shifts_from_measurements
+from .utils import sync_shifts_batch
 
 
 def tdoa_stream(bases: Sequence[np.ndarray], delays: Sequence[np.ndarray], gains: Sequence[np.ndarray], fs: float,
                 totals: Sequence[int], trim_len: int, filter_method: str = "butterworth",
                 max_expected_delay: Optional[float] = None, engine: Optional[Engine] = None,
-                frames_per_batch: int = 128) -> Tuple[np.ndarray, np.ndarray]:
+                frames_per_batch: int = 128, timings: Optional[Dict[str, float]] = None) -> Tuple[np.ndarray, np.ndarray]:
     """bases[F][nbase], delays / gains[F][M][K], totals[F] (main.py:102) -> (tables[F][P], lengths[F]).
 
     ``trim_len`` = int(duration * fs) (main.py:119-120).  ``frames_per_batch`` bounds the HBM held by one batch
-    (waveforms of a batch: 3 buffers of frames x M x L doubles)."""
+    (waveforms of a batch: 3 buffers of frames x M x L doubles).  ``timings`` (diagnostics): a dict that receives the
+    seconds spent per stage; the device is synchronised at every stage boundary while it is given."""
+    import time
     eng = engine or default_engine()
+    clock = [time.perf_counter()]
+
+    def lap(stage: str) -> None:
+        if timings is None:
+            return
+        eng.synchronize()
+        now = time.perf_counter()
+        timings[stage] = timings.get(stage, 0.0) + now - clock[0]
+        clock[0] = now
+
     nf = len(bases)
     if not (len(delays) == len(gains) == len(totals) == nf) or nf == 0:
         raise ValueError("one base, path table and total length per frame")
@@ -81,12 +93,12 @@ def tdoa_stream(bases: Sequence[np.ndarray], delays: Sequence[np.ndarray], gains
                         eng.free(d_base); eng.free(d_dl); eng.free(d_gn)
                         if not contiguous:
                             eng.free(d_part)
+                lap("simulate")
                 ref, kpk, win, pk, refpk = eng.sync_measure_dev(d_sim, b, m, out_len)                          # utils.py:413-427
-                pads = np.zeros((b, m), dtype=np.int32)
-                for q in range(b):                                                                            # utils.py:428-451
-                    shifts = sync_shifts_from_measurements(kpk[q], win[q], pk[q], refpk[q], int(ref[q]), [out_len] * m, out_len, fs)
-                    lowest = min(shifts)
-                    pads[q] = [max(0, int(round(sh - lowest))) for sh in shifts]
+                lap("sync_measure")
+                shifts = sync_shifts_batch(kpk, win, pk, refpk, ref, out_len, fs)                             # utils.py:428-446
+                pads = np.maximum(0, np.rint(shifts - shifts.min(axis=1, keepdims=True))).astype(np.int32)    # utils.py:448-451
+                lap("host_spline")
                 # one buffer for the whole batch: the frames of one synchronised length L sit together ([frames][M][L]) so
                 # that each length is one pair-table call, and ALL rows go through the prefilter in ONE launch (one lane
                 # per row: a launch takes as long for 64 rows as for 65 536)
@@ -113,16 +125,19 @@ def tdoa_stream(bases: Sequence[np.ndarray], delays: Sequence[np.ndarray], gains
                                                    d_al + (base_d + i * m * length) * 8)
                         offs.extend(base_d + k * length for k in range(nb * m))
                         lens.extend([length] * (nb * m))
+                    lap("align")
                     if design is None:                                                                         # main.py:191
                         for length, local in by_len.items():
                             eng.wiener3_dev(d_al + region[length] * 8, len(local) * m, length, d_flt + region[length] * 8)
                     else:
                         eng.filtfilt_ragged_dev(design[0], design[1], design[2], d_al, d_flt, offs, offs, lens)
+                    lap("prefilter")
                     row0 = 0
                     for length, local in by_len.items():                                                       # main.py:202-228
                         eng.gcc_phat_all_pairs_dev(d_flt + region[length] * 8, len(local), m, length, prm, d_tab + row0 * npairs * RECORD.itemsize)
                         row0 += len(local)
                     eng.synchronize()
+                    lap("pairs")
                     got = np.zeros((b, npairs), dtype=RECORD)
                     eng.download(got, d_tab)
                     row0 = 0
@@ -131,6 +146,7 @@ def tdoa_stream(bases: Sequence[np.ndarray], delays: Sequence[np.ndarray], gains
                             tables[group[q]] = got[row0 + i]
                             lengths[group[q]] = length
                         row0 += len(local)
+                    lap("download")
                 finally:
                     eng.free(d_al); eng.free(d_flt); eng.free(d_tab)
             finally:

@@ -115,3 +115,30 @@ def test_analytic_jacobian_matches_differences():
     num = np.stack([(residuals(x + e, mics, pairs, td, 343.62, w) - residuals(x - e, mics, pairs, td, 343.62, w)) / 2e-6
                     for e in np.eye(3) * 1e-6], axis=1)
     assert np.max(np.abs(jac - num)) < 1e-8
+
+
+def test_batched_sync_spline_equals_the_per_row_calls():
+    """stream.py refines the synchronisation peaks of a whole batch with one CubicSpline call per distinct peak index
+    (utils.sync_shifts_batch); the staged path makes the reference's call per row (utils.py:428-437).  Same shifts bit for
+    bit - symmetric windows (ties of the 100-point argmax), low peaks (not refined), implausible shifts
+    (zeroed) and the reference rows included."""
+    from pyaudiolocalization_amd.utils import sync_shifts_batch, sync_shifts_from_measurements
+    rng = np.random.default_rng(11)
+    b, m, length, fs = 6, 16, 12000, 48000.0
+    kpk = (length - 1 + rng.integers(-40, 41, size=(b, m))).astype(np.int32)
+    win = rng.standard_normal((b, m, 5))
+    win[:, :, 2] += 4.0
+    win[0, :4, 3:] = win[0, :4, 1::-1]                          # symmetric around the peak: the argmax of |spline| ties
+    pkabs = np.abs(win[:, :, 2])
+    ref_peak = np.full(b, 3.0)
+    pkabs[1, 2] = 0.1                                           # low peak: shift kept unrefined
+    kpk[2, 5] = length - 1 + 3000                               # > 50 ms: zeroed
+    kpk[3, 7] = 1                                               # too close to the edge for the five-point window
+    ref_idx = rng.integers(0, m, size=b)
+    got = sync_shifts_batch(kpk, win, pkabs, ref_peak, ref_idx, length, fs)
+    for q in range(b):
+        want = sync_shifts_from_measurements(kpk[q], win[q], pkabs[q], ref_peak[q], int(ref_idx[q]), [length] * m, length, fs)
+        assert np.array_equal(got[q], np.asarray(want, dtype=np.float64)), q
+        lowest = min(want)
+        pads = [max(0, int(round(sh - lowest))) for sh in want]
+        assert np.array_equal(np.maximum(0, np.rint(got[q] - got[q].min())).astype(np.int32), pads)
