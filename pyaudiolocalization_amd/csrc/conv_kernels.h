@@ -20,6 +20,29 @@ __global__ void k_make_chirp(cd* w, int n, int mult);
 __global__ void k_make_roots(cd* out, int count, double denom);
 __global__ void k_make_stage_tw(cd* out, int ln, bool compact);
 
+// Which (transform g, row or tile k1) a workgroup of a pass takes whose work list is row-major, transform-minor: all G
+// workgroups of one row read the same shared data (a row of every microphone's spectrum in the prime-factor row passes,
+// the spectrum elements of a column tile in the four-step loaders, a tile of the chirp spectrum in k_rows).  Workgroups
+// are dealt to the 8 XCDs round-robin (blockIdx % 8), so in plain order every XCD's L2 ends up fetching all of it; with
+// `xcd` the XCD x takes the x-th contiguous eighth of the list instead (5-6 rows of 45 at the metric length: each
+// spectrum row crosses the fabric once per launch, not once per XCD).  The grid is 8 * ceil(total / 8); false = nothing
+// to do (wave-uniform, before any barrier).
+__device__ __forceinline__ bool row_work_item(unsigned b, int G, int rows, int xcd, int& g, int& k1) {
+  const unsigned total = unsigned(G) * unsigned(rows);
+  unsigned w = b;
+  if (xcd) {
+    const unsigned per = (total + 7u) >> 3;
+    w = (b & 7u) * per + (b >> 3);
+  }
+  g = int(w % unsigned(G));
+  k1 = int(w / unsigned(G));
+  return w < total;
+}
+__host__ inline unsigned row_work_grid(int G, int rows, int xcd) {
+  const unsigned total = unsigned(G) * unsigned(rows);
+  return xcd ? 8u * ((total + 7u) >> 3) : total;
+}
+
 // exp(-2 pi i e / M) for e < M from the two root tables (e = q * M2 + r)
 __device__ __forceinline__ cd four_step_twiddle(unsigned e, int l2, const cd* __restrict__ twA, const cd* __restrict__ twB) {
   return cmul(twA[e >> l2], twB[e & ((1u << l2) - 1)]);
@@ -150,13 +173,14 @@ template <int LN, int LANES> __device__ __forceinline__ void copy_tw(cd* tw, con
 template <int L1, class Loader>
 __global__ __launch_bounds__(256) void k_cols_fwd(Loader ld, cd* __restrict__ W, int l2, int G,
                                                   const cd* __restrict__ tws, const cd* __restrict__ twA,
-                                                  const cd* __restrict__ twB) {
+                                                  const cd* __restrict__ twB, int tiles, int xcd) {
   constexpr int N1 = 1 << L1, T = kPoints / N1;
   __shared__ cd data[kPoints];
   __shared__ cd tw[N1];
   const int tid = threadIdx.x;
-  const int g = blockIdx.x % G;
-  const unsigned c0 = (blockIdx.x / G) * T;
+  int g, tile;
+  if (!row_work_item(blockIdx.x, G, tiles, xcd, g, tile)) return;
+  const unsigned c0 = unsigned(tile) * T;
   copy_tw<L1, kLanes>(tw, tws, tid);
   wg_fft<L1, true, false, T>(data, tw, tid, ColsFromLoader<Loader>{ld, g, l2, c0},
                              ColsToGlobal{W + (size_t(g) << (L1 + l2)), l2, c0, twA, twB});
@@ -165,13 +189,14 @@ __global__ __launch_bounds__(256) void k_cols_fwd(Loader ld, cd* __restrict__ W,
 // rows of length 2^L2; `m` = points per transform (any multiple of 4096)
 template <int L2, bool CONV>
 __global__ __launch_bounds__(256) void k_rows(cd* __restrict__ W, const cd* __restrict__ chat, size_t m, int G,
-                                              const cd* __restrict__ tws, double scale) {
+                                              const cd* __restrict__ tws, double scale, int tiles, int xcd) {
   constexpr int N2 = 1 << L2, T = kPoints / N2;
   __shared__ cd data[kPoints];
   __shared__ cd tw[N2];
   const int tid = threadIdx.x;
-  const int g = blockIdx.x % G;
-  const size_t tile = blockIdx.x / G;                       // 4096 consecutive points = 4096/N2 rows
+  int g, tile_i;
+  if (!row_work_item(blockIdx.x, G, tiles, xcd, g, tile_i)) return;
+  const size_t tile = size_t(tile_i);                       // 4096 consecutive points = 4096/N2 rows
   copy_tw<L2, kLanes>(tw, tws, tid);
   cd* base = W + size_t(g) * m + tile * kPoints;
   if (CONV) {
@@ -205,13 +230,14 @@ constexpr int kPoints3 = 3072, kLanes3 = 192;
 template <int LN, class Loader>
 __global__ __launch_bounds__(192) void k_cols3_fwd(Loader ld, cd* __restrict__ W, int l2, int G,
                                                    const cd* __restrict__ tws, const cd* __restrict__ twA,
-                                                   const cd* __restrict__ twB) {
+                                                   const cd* __restrict__ twB, int tiles, int xcd) {
   constexpr int N = 1 << LN, T = 1024 / N, NSUB = 3 * T;
   __shared__ cd data[kPoints3];
   __shared__ cd tw[N < 16 ? 16 : N];
   const int tid = threadIdx.x;
-  const int g = blockIdx.x % G;
-  const unsigned c0 = (blockIdx.x / G) * T;
+  int g, tile;
+  if (!row_work_item(blockIdx.x, G, tiles, xcd, g, tile)) return;
+  const unsigned c0 = unsigned(tile) * T;
   for (int i = tid; i < stage_tw_size(LN); i += kLanes3) tw[i] = tws[i];
   const auto rows3 = [&](int q, int c, int e) { return ld(g, (unsigned(q * N + e) << l2) + c0 + c); };
   const LdsTile3<LN, T> tile3{data};
@@ -268,13 +294,13 @@ static int launch_cols_fwd(Engine* e, const Conv& c, int G, Loader ld, cd* W, hi
   snprintf(name, sizeof name, "k_cols%s_fwd<%d,%s>", c.r3 ? "3" : "", c.l1, Loader::kName);
   ProfScope ps(e, name, on);
   if (c.r3) {
-    const unsigned grid = unsigned(size_t(G) * (c.M() / kPoints3));
-    PAL_SWITCH_L3(c.l1, k_cols3_fwd<LL, Loader><<<dim3(grid), dim3(kLanes3), 0, on>>>(ld, W, c.l2, G, e->stage_table(LL),
-                                                                                              c.twA, c.twB));
+    const int tiles = int(c.M() / kPoints3), xcd = e->xcd_rows && G > 1;
+    PAL_SWITCH_L3(c.l1, k_cols3_fwd<LL, Loader><<<dim3(row_work_grid(G, tiles, xcd)), dim3(kLanes3), 0, on>>>(
+                            ld, W, c.l2, G, e->stage_table(LL), c.twA, c.twB, tiles, xcd));
   } else {
-    const unsigned grid = unsigned(size_t(G) * (c.M() / kPoints));
-    PAL_SWITCH_L(c.l1, k_cols_fwd<LL, Loader><<<dim3(grid), dim3(kLanes), 0, on>>>(ld, W, c.l2, G, e->stage_table(LL),
-                                                                                          c.twA, c.twB));
+    const int tiles = int(c.M() / kPoints), xcd = e->xcd_rows && G > 1;
+    PAL_SWITCH_L(c.l1, k_cols_fwd<LL, Loader><<<dim3(row_work_grid(G, tiles, xcd)), dim3(kLanes), 0, on>>>(
+                           ld, W, c.l2, G, e->stage_table(LL), c.twA, c.twB, tiles, xcd));
   }
   return e->check(hipGetLastError(), "k_cols_fwd");
 }
@@ -284,11 +310,12 @@ static int launch_rows(Engine* e, const Conv& c, int G, cd* W, bool conv, double
   char name[64];
   snprintf(name, sizeof name, "k_rows<%d,%s>", c.l2, conv ? "conv" : "fwd");
   ProfScope ps(e, name, on);
-  const unsigned grid = unsigned(size_t(G) * (c.M() / kPoints));
+  const int tiles = int(c.M() / kPoints), xcd = e->xcd_rows && G > 1;
+  const unsigned grid = row_work_grid(G, tiles, xcd);
   if (conv) {
-    PAL_SWITCH_L(c.l2, k_rows<LL, true><<<dim3(grid), dim3(kLanes), 0, on>>>(W, c.chat, c.M(), G, e->stage_table(LL), scale));
+    PAL_SWITCH_L(c.l2, k_rows<LL, true><<<dim3(grid), dim3(kLanes), 0, on>>>(W, c.chat, c.M(), G, e->stage_table(LL), scale, tiles, xcd));
   } else {
-    PAL_SWITCH_L(c.l2, k_rows<LL, false><<<dim3(grid), dim3(kLanes), 0, on>>>(W, c.chat, c.M(), G, e->stage_table(LL), scale));
+    PAL_SWITCH_L(c.l2, k_rows<LL, false><<<dim3(grid), dim3(kLanes), 0, on>>>(W, c.chat, c.M(), G, e->stage_table(LL), scale, tiles, xcd));
   }
   return e->check(hipGetLastError(), "k_rows");
 }

@@ -62,27 +62,6 @@ struct PfaRowsArgs {
   int xcd;             // 1: XCD-aware order of the workgroups (row_work_item)
 };
 
-// Which (transform g, row k1) a workgroup of a row pass takes.  The work list is row-major, transform-minor: all G
-// workgroups of one row read the same row of every microphone's spectrum.  Workgroups are dealt to the 8 XCDs round-robin
-// (blockIdx % 8), so in plain order every XCD's L2 ends up fetching every spectrum row; with `xcd` the XCD x takes the
-// x-th contiguous eighth of the list instead (5-6 rows of 45 at the metric length: each spectrum row crosses the fabric
-// once per launch, not once per XCD).  The grid is 8 * ceil(total / 8); false = nothing to do (wave-uniform, before any barrier).
-__device__ __forceinline__ bool row_work_item(unsigned b, int G, int rows, int xcd, int& g, int& k1) {
-  const unsigned total = unsigned(G) * unsigned(rows);
-  unsigned w = b;
-  if (xcd) {
-    const unsigned per = (total + 7u) >> 3;
-    w = (b & 7u) * per + (b >> 3);
-  }
-  g = int(w % unsigned(G));
-  k1 = int(w / unsigned(G));
-  return w < total;
-}
-__host__ inline unsigned row_work_grid(int G, int rows, int xcd) {
-  const unsigned total = unsigned(G) * unsigned(rows);
-  return xcd ? 8u * ((total + 7u) >> 3) : total;
-}
-
 // v_permlane32_swap(x, y): x' = {x[0:31], y[0:31]}, y' = {x[32:63], y[32:63]} (lane ranges of the two results).
 // swap_pair(a, b, lo, hi):  lo = lanes 0-31 keep a, lanes 32-63 receive b of their partner lane (lane - 32);
 //                           hi = lanes 0-31 receive a of their partner lane (lane + 32), lanes 32-63 keep b
