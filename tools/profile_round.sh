@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- p
 PMC_CMD="python3 $ROOT/bench.py --steps 2 --warmup 1 --frames 16 --no-cpu-baseline --no-kernel-events"
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "flops SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS"; do
   set -- $pass; name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc/$name -o $name --output-format csv -- $PMC_CMD > $OUT/pmc_$name.log 2>&1 || echo "pass $name failed"
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc/$name -o $name --output-format csv -- $PMC_CMD > $OUT/pmc_$name.log 2>&1 || echo "pass $name failed"
 done
 python3 $ROOT/tools/pmc_summary.py $OUT/pmc $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1
 for cfg in c2 c3 c4 c5; do
