@@ -270,7 +270,32 @@ int Engine::alloc_conv(Conv& c, size_t needed) {
       c.l2 = l2;
     }
   }
-  if (!stage_table(c.l1) || !stage_table(c.l2)) return fail(PAL_ERR_NOMEM, "twiddle tables");
+  // Register-resident rows (conv_kernels.h k_colsreg_* / k_rowsreg) where the columns then fit one lane comfortably:
+  // rows of 4096 points if that leaves 12 ... 24-point columns, else rows of 8192 points for 6 ... 24-point columns
+  // (measured on C2 / C3 / C5 and at n = 88 203 with the prime-factor route off: +13 ... +19 % over the LDS-tile passes either
+  // way, the shorter rows ahead where both fit; 32- and 48-point columns need 250 registers per lane and gain nothing:
+  // C4's 393 216 = 48 x 8192 stays on the LDS tiles).  PAL_FOUR_REG = 12 / 13 forces a row length, 0 turns the route off.
+  c.reg = false;
+  if (four_reg != 0) {
+    const auto cols_ok = [&](int lr, bool wide) {
+      if (c.m % (size_t(1) << lr)) return false;
+      const size_t m1 = c.m >> lr;
+      if (lr == 12 && m1 < 12) return false;
+      return m1 == 6 || m1 == 8 || m1 == 12 || m1 == 16 || m1 == 24 || (wide && (m1 == 32 || m1 == 48));
+    };
+    int lr = 0;
+    if (four_reg == 12 || four_reg == 13) lr = cols_ok(four_reg, true) ? four_reg : 0;
+    else lr = cols_ok(12, false) ? 12 : (cols_ok(13, false) ? 13 : 0);
+    if (lr) {
+      c.reg = true;
+      c.m1r = int(c.m >> lr);
+      c.l2 = lr;
+      c.l1 = 0;
+      c.r3 = false;
+      if (!stage_table(lr)) return fail(PAL_ERR_NOMEM, "twiddle tables");
+    }
+  }
+  if (!c.reg && (!stage_table(c.l1) || !stage_table(c.l2))) return fail(PAL_ERR_NOMEM, "twiddle tables");
   PAL_HIP(hipMalloc(&c.chat, c.m * sizeof(cd)));
   PAL_HIP(hipMalloc(&c.twA, sizeof(cd) * c.M1()));
   PAL_HIP(hipMalloc(&c.twB, sizeof(cd) << c.l2));

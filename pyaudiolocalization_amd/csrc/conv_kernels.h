@@ -13,6 +13,7 @@
 // between stages.
 #pragma once
 #include "engine.h"
+#include "reg_fft.h"
 
 namespace pal {
 
@@ -265,6 +266,128 @@ __global__ __launch_bounds__(192) void k_cols3_inv(const cd* __restrict__ W, Sto
   for (int w = tid; w < N * T; w += kLanes3) radix3_item<T, true>(tile3, rows3, twA, w);
 }
 
+// ------------------------------------------------------------------ the three passes with 8192-point rows (M = M1 x 8192)
+// Convolution lengths from 49 152 to 393 216 points (frames of 12 000 ... 96 000 samples) can be cut with rows of 8192
+// points, which leaves columns of only M1 = 6 ... 48 points:
+//   - a column then fits the registers of ONE lane (reg_fft.h reg_dft): lane = column, 256 consecutive columns per
+//     workgroup, every load and store of a wavefront is one contiguous 1 KB request, no LDS, no barrier - the column
+//     passes are plain streaming kernels with M1 loads in flight per lane (against 16-column tiles of 192 rows moved
+//     through LDS by 192-lane workgroups, three per CU, whose wavefronts waited on memory 65-70 % of the time);
+//   - a row is one register-resident 8192-point transform (reg_fft.h big_fft: 256 lanes x 32 points, LDS only for the
+//     stage exchanges, two workgroups per CU), forward x chirp spectrum x inverse without leaving the registers.
+// The four-step twiddle exp(-/+ 2 pi i c k1 / M) of column c is looked up exactly at k1 = 1 and at every fourth k1 and
+// completed by at most two multiplications (w^(4j+i) = w^(4j) w^i).
+constexpr int kRegCols = 256;
+
+template <int M1, int kRegL2, bool INV>
+__device__ __forceinline__ void colsreg_twiddle(cd* v, unsigned c, const cd* __restrict__ twA, const cd* __restrict__ twB) {
+  const cd w1 = twB[c];                                        // c < 2^L2: exp(-2 pi i c / M)
+  const cd w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+#pragma unroll
+  for (int k1 = 1; k1 < M1; ++k1) {
+    cd w;
+    if (k1 < 4) w = k1 == 1 ? w1 : (k1 == 2 ? w2 : w3);
+    else {
+      const cd anchor = four_step_twiddle(c * unsigned(k1 & ~3), kRegL2, twA, twB);
+      w = (k1 & 3) == 0 ? anchor : cmul(anchor, (k1 & 3) == 1 ? w1 : ((k1 & 3) == 2 ? w2 : w3));
+    }
+    v[k1] = INV ? cmulc(v[k1], w) : cmul(v[k1], w);
+  }
+}
+
+template <int M1, int kRegL2, class Loader>
+__global__ __launch_bounds__(kRegCols) void k_colsreg_fwd(Loader ld, cd* __restrict__ W, int G, const cd* __restrict__ twA,
+                                                          const cd* __restrict__ twB, int xcd) {
+  int g, tile;
+  if (!row_work_item(blockIdx.x, G, (1 << kRegL2) / kRegCols, xcd, g, tile)) return;
+  const unsigned c = unsigned(tile) * kRegCols + threadIdx.x;
+  cd v[M1];
+#pragma unroll
+  for (int r = 0; r < M1; ++r) v[r] = ld(g, (unsigned(r) << kRegL2) + c);
+  reg_dft<M1, false>(v, twA);
+  colsreg_twiddle<M1, kRegL2, false>(v, c, twA, twB);
+  cd* out = W + (size_t(g) * M1 << kRegL2) + c;
+#pragma unroll
+  for (int k1 = 0; k1 < M1; ++k1) out[size_t(k1) << kRegL2] = v[k1];
+}
+
+template <int M1, int kRegL2, class Storer>
+__global__ __launch_bounds__(kRegCols) void k_colsreg_inv(const cd* __restrict__ W, Storer st, int G, const cd* __restrict__ twA,
+                                                          const cd* __restrict__ twB, int xcd) {
+  int g, tile;
+  if (!row_work_item(blockIdx.x, G, (1 << kRegL2) / kRegCols, xcd, g, tile)) return;
+  const unsigned c = unsigned(tile) * kRegCols + threadIdx.x;
+  const cd* in = W + (size_t(g) * M1 << kRegL2) + c;
+  cd v[M1];
+#pragma unroll
+  for (int k1 = 0; k1 < M1; ++k1) v[k1] = in[size_t(k1) << kRegL2];
+  colsreg_twiddle<M1, kRegL2, true>(v, c, twA, twB);
+  reg_dft<M1, true>(v, twA);
+#pragma unroll
+  for (int r = 0; r < M1; ++r) st(g, (unsigned(r) << kRegL2) + c, v[r]);
+}
+
+// rows of 8192 points: one workgroup per row.  CONV: forward, x chirp spectrum, inverse, in place; else forward x scale.
+template <int kRegL2, bool CONV>
+__global__ __launch_bounds__((BigTile<kRegL2, 32>::kLanes)) __attribute__((amdgpu_waves_per_eu(2)))
+void k_rowsreg(cd* __restrict__ W, const cd* __restrict__ chat, int rows, int G, const cd* __restrict__ tws, double scale, int xcd) {
+  using B = BigTile<kRegL2, 32>;
+  constexpr int N2 = 1 << kRegL2, LANES = B::kLanes, PTS = 32;
+  __shared__ double plane[N2];
+  const int tid = threadIdx.x;
+  int g, row;
+  if (!row_work_item(blockIdx.x, G, rows, xcd, g, row)) return;
+  cd* const base = W + ((size_t(g) * rows + row) << kRegL2);
+  cd v[PTS];
+#pragma unroll
+  for (int s = 0; s < PTS; ++s) v[B::reg_of(s, B::kR0)] = base[tid + LANES * s];
+  big_fft<kRegL2, PTS, false>(plane, tws, v, tid);
+  if constexpr (CONV) {
+    const cd* const ch = chat + (size_t(row) << kRegL2);
+    {
+      cd u[PTS];
+#pragma unroll
+      for (int reg = 0; reg < PTS; ++reg) {
+        if (reg % 8 == 0) asm volatile("" ::: "memory");      // eight chirp-spectrum loads in flight, not all 32
+        const int s = B::slot_of(reg, B::kRL);
+        u[B::reg_of(s, B::kR0)] = cmul(v[reg], ch[tid + LANES * s]);
+      }
+#pragma unroll
+      for (int r = 0; r < PTS; ++r) v[r] = u[r];
+    }
+    {
+      // (opaque copies of the table offset and the lane index: seen through the same values the compiler keeps the forward
+      //  transform's twiddles and LDS positions live for the inverse one and spills them - pfa_big.h)
+      size_t again = 0;
+      int tid2 = tid;
+      asm volatile("" : "+s"(again), "+v"(tid2));
+      big_fft<kRegL2, PTS, true>(plane, tws + again, v, tid2);
+    }
+#pragma unroll
+    for (int reg = 0; reg < PTS; ++reg) base[tid + LANES * B::slot_of(reg, B::kRL)] = v[reg];
+  } else {
+#pragma unroll
+    for (int reg = 0; reg < PTS; ++reg) base[tid + LANES * B::slot_of(reg, B::kRL)] = cscale(v[reg], scale);
+  }
+}
+
+#define PAL_SWITCH_M1(m1, l2, ...)                                 \
+  switch ((l2) * 100 + (m1)) {                                     \
+    case 1306: { constexpr int MM = 6, LR = 13; __VA_ARGS__; } break;   \
+    case 1308: { constexpr int MM = 8, LR = 13; __VA_ARGS__; } break;   \
+    case 1312: { constexpr int MM = 12, LR = 13; __VA_ARGS__; } break;  \
+    case 1316: { constexpr int MM = 16, LR = 13; __VA_ARGS__; } break;  \
+    case 1324: { constexpr int MM = 24, LR = 13; __VA_ARGS__; } break;  \
+    case 1332: { constexpr int MM = 32, LR = 13; __VA_ARGS__; } break;  \
+    case 1348: { constexpr int MM = 48, LR = 13; __VA_ARGS__; } break;  \
+    case 1212: { constexpr int MM = 12, LR = 12; __VA_ARGS__; } break;  \
+    case 1216: { constexpr int MM = 16, LR = 12; __VA_ARGS__; } break;  \
+    case 1224: { constexpr int MM = 24, LR = 12; __VA_ARGS__; } break;  \
+    case 1232: { constexpr int MM = 32, LR = 12; __VA_ARGS__; } break;  \
+    case 1248: { constexpr int MM = 48, LR = 12; __VA_ARGS__; } break;  \
+    default: return e->fail(PAL_ERR_INTERNAL, "register column pass of %d points, rows of 2^%d", m1, l2); \
+  }
+
 // ------------------------------------------------------------------ launch helpers
 #define PAL_SWITCH_L(l, ...)                                       \
   switch (l) {                                                     \
@@ -291,9 +414,14 @@ template <class Loader>
 static int launch_cols_fwd(Engine* e, const Conv& c, int G, Loader ld, cd* W, hipStream_t on = nullptr) {
   if (!on) on = e->stream;
   char name[64];
-  snprintf(name, sizeof name, "k_cols%s_fwd<%d,%s>", c.r3 ? "3" : "", c.l1, Loader::kName);
+  if (c.reg) snprintf(name, sizeof name, "k_colsreg_fwd<%d,%s>", c.M1(), Loader::kName);
+  else snprintf(name, sizeof name, "k_cols%s_fwd<%d,%s>", c.r3 ? "3" : "", c.l1, Loader::kName);
   ProfScope ps(e, name, on);
-  if (c.r3) {
+  if (c.reg) {
+    const int xcd = e->xcd_rows && G > 1;
+    const unsigned grid = row_work_grid(G, (1 << c.l2) / kRegCols, xcd);
+    PAL_SWITCH_M1(c.M1(), c.l2, k_colsreg_fwd<MM, LR, Loader><<<dim3(grid), dim3(kRegCols), 0, on>>>(ld, W, G, c.twA, c.twB, xcd));
+  } else if (c.r3) {
     const int tiles = int(c.M() / kPoints3), xcd = e->xcd_rows && G > 1;
     PAL_SWITCH_L3(c.l1, k_cols3_fwd<LL, Loader><<<dim3(row_work_grid(G, tiles, xcd)), dim3(kLanes3), 0, on>>>(
                             ld, W, c.l2, G, e->stage_table(LL), c.twA, c.twB, tiles, xcd));
@@ -308,11 +436,24 @@ static int launch_cols_fwd(Engine* e, const Conv& c, int G, Loader ld, cd* W, hi
 static int launch_rows(Engine* e, const Conv& c, int G, cd* W, bool conv, double scale, hipStream_t on = nullptr) {
   if (!on) on = e->stream;
   char name[64];
-  snprintf(name, sizeof name, "k_rows<%d,%s>", c.l2, conv ? "conv" : "fwd");
+  snprintf(name, sizeof name, c.reg ? "k_rowsreg<%d,%s>" : "k_rows<%d,%s>", c.l2, conv ? "conv" : "fwd");
   ProfScope ps(e, name, on);
   const int tiles = int(c.M() / kPoints), xcd = e->xcd_rows && G > 1;
   const unsigned grid = row_work_grid(G, tiles, xcd);
-  if (conv) {
+  if (c.reg) {
+    const cd* tws = e->stage_table(c.l2);
+    if (!tws) return e->fail(PAL_ERR_NOMEM, "twiddle tables");
+    const unsigned rgrid = row_work_grid(G, c.M1(), xcd);
+    if (c.l2 == 13) {
+      constexpr int lanes = BigTile<13, 32>::kLanes;
+      if (conv) k_rowsreg<13, true><<<dim3(rgrid), dim3(lanes), 0, on>>>(W, c.chat, c.M1(), G, tws, scale, xcd);
+      else k_rowsreg<13, false><<<dim3(rgrid), dim3(lanes), 0, on>>>(W, c.chat, c.M1(), G, tws, scale, xcd);
+    } else {
+      constexpr int lanes = BigTile<12, 32>::kLanes;
+      if (conv) k_rowsreg<12, true><<<dim3(rgrid), dim3(lanes), 0, on>>>(W, c.chat, c.M1(), G, tws, scale, xcd);
+      else k_rowsreg<12, false><<<dim3(rgrid), dim3(lanes), 0, on>>>(W, c.chat, c.M1(), G, tws, scale, xcd);
+    }
+  } else if (conv) {
     PAL_SWITCH_L(c.l2, k_rows<LL, true><<<dim3(grid), dim3(kLanes), 0, on>>>(W, c.chat, c.M(), G, e->stage_table(LL), scale, tiles, xcd));
   } else {
     PAL_SWITCH_L(c.l2, k_rows<LL, false><<<dim3(grid), dim3(kLanes), 0, on>>>(W, c.chat, c.M(), G, e->stage_table(LL), scale, tiles, xcd));
@@ -324,9 +465,14 @@ template <class Storer>
 static int launch_cols_inv(Engine* e, const Conv& c, int G, const cd* W, Storer st, hipStream_t on = nullptr) {
   if (!on) on = e->stream;
   char name[64];
-  snprintf(name, sizeof name, "k_cols%s_inv<%d,%s>", c.r3 ? "3" : "", c.l1, Storer::kName);
+  if (c.reg) snprintf(name, sizeof name, "k_colsreg_inv<%d,%s>", c.M1(), Storer::kName);
+  else snprintf(name, sizeof name, "k_cols%s_inv<%d,%s>", c.r3 ? "3" : "", c.l1, Storer::kName);
   ProfScope ps(e, name, on);
-  if (c.r3) {
+  if (c.reg) {
+    const int xcd = e->xcd_rows && G > 1;
+    const unsigned grid = row_work_grid(G, (1 << c.l2) / kRegCols, xcd);
+    PAL_SWITCH_M1(c.M1(), c.l2, k_colsreg_inv<MM, LR, Storer><<<dim3(grid), dim3(kRegCols), 0, on>>>(W, st, G, c.twA, c.twB, xcd));
+  } else if (c.r3) {
     const unsigned grid = unsigned(size_t(G) * (c.M() / kPoints3));
     PAL_SWITCH_L3(c.l1, k_cols3_inv<LL, Storer><<<dim3(grid), dim3(kLanes3), 0, on>>>(W, st, c.l2, G, e->stage_table(LL),
                                                                                               c.twA, c.twB));

@@ -22,12 +22,14 @@ struct PeakArgs;    // peak_types.h
 struct Conv {
   int l1 = 0, l2 = 0;
   bool r3 = false;
+  bool reg = false;              // rows of 8192 points in registers, columns of m1r points in the registers of one lane (conv_kernels.h)
+  int m1r = 0;
   size_t m = 0;                  // points per transform
   cd* chat = nullptr;            // FFT_M of the chirp kernel in [k1][k2] order, pre-scaled
   cd* twA = nullptr;             // exp(-2 pi i q / M1), q < M1
   cd* twB = nullptr;             // exp(-2 pi i r / M),  r < M2
   size_t M() const { return m; }
-  int M1() const { return (r3 ? 3 : 1) << l1; }
+  int M1() const { return reg ? m1r : (r3 ? 3 : 1) << l1; }
   int M2() const { return 1 << l2; }
 };
 
@@ -87,6 +89,7 @@ struct Engine {
   bool allow_r3 = true;            // PAL_RADIX3=0 forces power-of-two convolution lengths
   bool allow_pfa = true;           // PAL_PFA=0 keeps the PHAT inverse on the four-step chirp convolution
   bool allow_rader = true;         // PAL_RADER=0 keeps the row pass on the in-LDS chirp convolution
+  int four_reg = -1;               // PAL_FOUR_REG: register-resident rows of the four-step route: -1 choose, 12 / 13 force 2^12 / 2^13, 0 = LDS tiles only
   bool xcd_rows = true;            // PAL_XCD_ROWS=0: row passes in plain workgroup order (pfa_kernels.h: row_work_item)
   bool allow_big = true;           // PAL_PFA_BIG=0: no register-resident row tiles (N2 <= 2048 only, as in round 1)
   int pfa_sub = 0;                 // transforms per row/column pass of the prime-factor route (PAL_PFA_SUB; 0 = whole group)

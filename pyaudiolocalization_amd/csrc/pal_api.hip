@@ -249,6 +249,8 @@ int pal_create(int device, pal_handle* out) {
   if (env) e->allow_rader = atoi(env) != 0;
   env = getenv("PAL_PFA_BIG");
   if (env) e->allow_big = atoi(env) != 0;
+  env = getenv("PAL_FOUR_REG");
+  if (env) e->four_reg = atoi(env);
   env = getenv("PAL_XCD_ROWS");
   if (env) e->xcd_rows = atoi(env) != 0;
   env = getenv("PAL_PFA_FWD");

@@ -87,7 +87,7 @@ int Engine::build_pfa(Plan& pl) {
   // 1024 / 2048 / 4096 points (two per workgroup), 0.050 / 0.145 for the register-resident tiles of 8192 / 16384 (pfa_big.h:
   // the 16384-point tile runs one workgroup per CU) - and the column pass 1.15e-5 n for its
   // traffic plus 4e-8 N1 n for the dense N1-point DFTs.  The four-step route: 1.6e-5 per point of its convolution for the
-  // first two passes, 2.2e-5 n for the last pass and the statistics launches.  A split that cannot take the fused column
+  // first two passes, 2.2e-5 n for the last pass and the statistics launches, x 0.86 with register-resident rows.  A split that cannot take the fused column
   // pass (more than four chunks of output indices: N1 > 89) must beat the four-step route by 15 %.
   static const double kTile[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.005, 0.0113, 0.026, 0.050, 0.145};
   double best = -1;
@@ -103,7 +103,7 @@ int Engine::build_pfa(Plan& pl) {
     if (chunks > 4) cost *= 1.15;
     if (best < 0 || cost < best) { best = cost; bn1 = int(d); bn2 = int(r); blm = lm; }
   }
-  const double four_step = 1.6e-5 * double(pl.inv.M()) + 2.2e-5 * double(n);
+  const double four_step = (1.6e-5 * double(pl.inv.M()) + 2.2e-5 * double(n)) * (pl.inv.reg ? 0.86 : 1.0);
   if (best < 0 || best > four_step) return PAL_OK;             // the four-step route is no worse
   // (short transforms are launch-bound, the model does not apply: there the split must also stay within 1.5 x the
   //  four-step route's points, round 1's rule)

@@ -32,6 +32,10 @@ template <int LM, int PTS> struct BigTile {
 
 // one stage on the PTS registers of a lane: PER = PTS / R butterflies (work items tid + LANES q), twiddles from the
 // stage-major table in global memory (L2-resident: 16 B x 2^LM)
+#ifndef PAL_BIG_TW_RECUR
+#define PAL_BIG_TW_RECUR 1   // twiddles of the radix-4 / radix-8 stages: rows 1, 2 (, 4) loaded, the others one product deep
+#endif
+
 template <int LM, int PTS, bool INV, int LP>
 __device__ __forceinline__ void big_stage(cd* v, const cd* __restrict__ tws, int tid) {
   constexpr int R = stage_radix(LM, LP), P = 1 << LP, LANES = BigTile<LM, PTS>::kLanes, PER = PTS / R;
@@ -40,10 +44,26 @@ __device__ __forceinline__ void big_stage(cd* v, const cd* __restrict__ tws, int
     if constexpr (P > 1) {
       const int k = (tid + LANES * q) & (P - 1);
       const cd* t = tws + stage_tw_offset(LM, LP) + k;
+      if constexpr (PAL_BIG_TW_RECUR && (R == 4 || R == 8)) {
+        // the tables of the late stages (P >= 256: 28 ... 200 KB) do not stay in L1: fewer loads, a few more products
+        cd f[R];
+        f[1] = t[0];
+        f[2] = t[P];
+        f[3] = cmul(f[1], f[2]);
+        if constexpr (R == 8) {
+          f[4] = t[3 * P];
+          f[5] = cmul(f[4], f[1]);
+          f[6] = cmul(f[4], f[2]);
+          f[7] = cmul(f[4], f[3]);
+        }
 #pragma unroll
-      for (int r = 1; r < R; ++r) {
-        const cd f = t[(r - 1) * P];
-        v[q * R + r] = INV ? cmulc(v[q * R + r], f) : cmul(v[q * R + r], f);
+        for (int r = 1; r < R; ++r) v[q * R + r] = INV ? cmulc(v[q * R + r], f[r]) : cmul(v[q * R + r], f[r]);
+      } else {
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+          const cd f = t[(r - 1) * P];
+          v[q * R + r] = INV ? cmulc(v[q * R + r], f) : cmul(v[q * R + r], f);
+        }
       }
     }
     dftR<R, INV>(v + q * R);
@@ -104,6 +124,68 @@ template <int LM, int PTS, bool INV>
 __device__ __forceinline__ void big_fft(double* plane, const cd* __restrict__ tws, cd* v, int tid) {
   static_assert(stage_radix(LM, 0) == 16, "radix-16 first stage");
   big_fft_from<LM, PTS, INV, 0>(plane, tws, v, tid);
+}
+
+// ------------------------------------------------------------------ small DFTs of one lane
+// N-point DFT of v[0 .. N) in natural order, N = 2^k <= 32 or 3 * 2^k <= 48, entirely in the registers of ONE lane (the
+// column transforms of the four-step route when its rows are 8192 points long: conv_kernels.h k_colsreg_*).
+// N = 3 P: 3-point butterflies over the inputs e, P + e, 2P + e, the twiddle exp(-/+ 2 pi i e s / N) on branch s, a P-point
+// DFT per branch; output 3 k' + s.  N = 32: the same with two branches.  `roots` = exp(-2 pi i m / N), m < N, read through
+// the scalar cache (wave-uniform, compile-time indices).
+__device__ __forceinline__ cd uniform_root(const cd* roots, int m) {
+  const auto* p = reinterpret_cast<const __attribute__((address_space(4))) double*>(reinterpret_cast<uintptr_t>(roots)) + 2 * m;
+  return mk(p[0], p[1]);
+}
+
+template <int N, bool INV>
+__device__ __forceinline__ void reg_dft(cd* v, const cd* roots) {
+  static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 3 || N == 6 || N == 12 || N == 24 || N == 48, "column length");
+  if constexpr (N == 1) {
+    return;
+  } else if constexpr (N == 2 || N == 4 || N == 8 || N == 16) {
+    dftR<N, INV>(v);
+  } else if constexpr (N == 32) {
+    constexpr int P = 16;
+    cd y[2][P];
+#pragma unroll
+    for (int e = 0; e < P; ++e) {
+      y[0][e] = v[e] + v[P + e];
+      const cd d = v[e] - v[P + e];
+      const cd w = uniform_root(roots, e);
+      y[1][e] = e == 0 ? d : (INV ? cmulc(d, w) : cmul(d, w));
+    }
+    dftR<P, INV>(y[0]);
+    dftR<P, INV>(y[1]);
+#pragma unroll
+    for (int k = 0; k < P; ++k) { v[2 * k] = y[0][k]; v[2 * k + 1] = y[1][k]; }
+  } else {
+    constexpr int P = N / 3;
+    const double h = 0.86602540378443864676;            // sin(pi/3)
+    cd y[3][P];
+#pragma unroll
+    for (int e = 0; e < P; ++e) {
+      const cd a0 = v[e], a1 = v[P + e], a2 = v[2 * P + e];
+      const cd sum = a1 + a2, dif = a1 - a2;
+      const cd mid = mk(a0.x - 0.5 * sum.x, a0.y - 0.5 * sum.y);
+      const cd rot = INV ? mk(-h * dif.y, h * dif.x) : mk(h * dif.y, -h * dif.x);   // (-/+ i sqrt(3)/2) (a1 - a2)
+      y[0][e] = a0 + sum;
+      cd y1 = mid + rot, y2 = mid - rot;
+      if (e > 0) {
+        const cd w1 = uniform_root(roots, e), w2 = uniform_root(roots, 2 * e);
+        y1 = INV ? cmulc(y1, w1) : cmul(y1, w1);
+        y2 = INV ? cmulc(y2, w2) : cmul(y2, w2);
+      }
+      y[1][e] = y1;
+      y[2][e] = y2;
+    }
+    if constexpr (P > 1) {
+      dftR<P, INV>(y[0]);
+      dftR<P, INV>(y[1]);
+      dftR<P, INV>(y[2]);
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) { v[3 * k] = y[0][k]; v[3 * k + 1] = y[1][k]; v[3 * k + 2] = y[2][k]; }
+  }
 }
 
 }  // namespace pal

@@ -21,6 +21,9 @@ def bench_name(kernel):
     k = re.sub(r"k_peak_finish<(true|false)>", "k_peak_finish", k)
     k = re.sub(r"k_rows<(\d+), true>", r"k_rows<\1,conv>", k)
     k = re.sub(r"k_rows<(\d+), false>", r"k_rows<\1,fwd>", k)
+    k = re.sub(r"k_rowsreg<(\d+), true>", r"k_rowsreg<\1,conv>", k)
+    k = re.sub(r"k_rowsreg<(\d+), false>", r"k_rowsreg<\1,fwd>", k)
+    k = re.sub(r"k_colsreg_(fwd|inv)<(\d+), \d+, ", r"k_colsreg_\1<\2,", k)
     return k.replace(", ", ",")
 
 
