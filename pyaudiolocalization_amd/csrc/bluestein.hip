@@ -270,29 +270,37 @@ int Engine::alloc_conv(Conv& c, size_t needed) {
       c.l2 = l2;
     }
   }
-  // Register-resident rows (conv_kernels.h k_colsreg_* / k_rowsreg) where the columns then fit one lane comfortably:
-  // rows of 4096 points if that leaves 12 ... 24-point columns, else rows of 8192 points for 6 ... 24-point columns
-  // (measured on C2 / C3 / C5 and at n = 88 203 with the prime-factor route off: +13 ... +19 % over the LDS-tile passes either
-  // way, the shorter rows ahead where both fit; 32- and 48-point columns need 250 registers per lane and gain nothing:
-  // C4's 393 216 = 48 x 8192 stays on the LDS tiles).  PAL_FOUR_REG = 12 / 13 forces a row length, 0 turns the route off.
+  // Register-resident rows (conv_kernels.h k_colsreg_* / k_rowsreg) where the columns then fit one lane comfortably: rows
+  // of 4096 points with 12 ... 24-point columns, or rows of 8192 points with 6 ... 24-point columns (measured on C2 / C3 / C5
+  // and at n = 88 203 with the prime-factor route off: +13 ... +19 % over the LDS-tile passes either way, the shorter rows
+  // ahead where both fit; 32- and 48-point columns need 250 registers per lane and gain nothing: C4's 393 216 = 48 x 8192
+  // stays on the LDS tiles).  A column length only needs a DFT that fits one lane - 2^a, 3 * 2^a, or 2 x 9 / 10 / 11
+  // (reg_fft.h reg_dft) - so the convolution length is the smallest M1 x 2^12 / 2^13 that holds the sequence, in steps
+  // of about 10 % instead of the 2^k / 3 * 2^k ladder (88 203 points: 22 x 8192 = 180 224 instead of 196 608).
+  // PAL_FOUR_REG = 12 / 13 forces a row length (columns up to 48 points then), 0 turns the route off.
   c.reg = false;
   if (four_reg != 0) {
-    const auto cols_ok = [&](int lr, bool wide) {
-      if (c.m % (size_t(1) << lr)) return false;
-      const size_t m1 = c.m >> lr;
-      if (lr == 12 && m1 < 12) return false;
-      return m1 == 6 || m1 == 8 || m1 == 12 || m1 == 16 || m1 == 24 || (wide && (m1 == 32 || m1 == 48));
-    };
-    int lr = 0;
-    if (four_reg == 12 || four_reg == 13) lr = cols_ok(four_reg, true) ? four_reg : 0;
-    else lr = cols_ok(12, false) ? 12 : (cols_ok(13, false) ? 13 : 0);
-    if (lr) {
+    static const int kCols[] = {6, 8, 12, 16, 18, 20, 22, 24, 32, 48};
+    size_t best_m = 0;
+    int best_lr = 0, best_m1 = 0;
+    for (int lr = 12; lr <= 13; ++lr) {
+      if ((four_reg == 12 || four_reg == 13) && lr != four_reg) continue;
+      for (int m1 : kCols) {
+        if (lr == 12 && m1 < 12) continue;
+        if (m1 > 24 && four_reg < 0) continue;
+        const size_t m = size_t(m1) << lr;
+        if (m < needed || m > c.m) continue;               // (never longer than the 2^k / 3 * 2^k choice)
+        if (!best_m || m < best_m) { best_m = m; best_lr = lr; best_m1 = m1; }   // ties: the shorter rows (lr = 12 comes first)
+      }
+    }
+    if (best_m) {
       c.reg = true;
-      c.m1r = int(c.m >> lr);
-      c.l2 = lr;
+      c.m = best_m;
+      c.m1r = best_m1;
+      c.l2 = best_lr;
       c.l1 = 0;
       c.r3 = false;
-      if (!stage_table(lr)) return fail(PAL_ERR_NOMEM, "twiddle tables");
+      if (!stage_table(best_lr)) return fail(PAL_ERR_NOMEM, "twiddle tables");
     }
   }
   if (!c.reg && (!stage_table(c.l1) || !stage_table(c.l2))) return fail(PAL_ERR_NOMEM, "twiddle tables");

@@ -377,11 +377,17 @@ void k_rowsreg(cd* __restrict__ W, const cd* __restrict__ chat, int rows, int G,
     case 1308: { constexpr int MM = 8, LR = 13; __VA_ARGS__; } break;   \
     case 1312: { constexpr int MM = 12, LR = 13; __VA_ARGS__; } break;  \
     case 1316: { constexpr int MM = 16, LR = 13; __VA_ARGS__; } break;  \
+    case 1318: { constexpr int MM = 18, LR = 13; __VA_ARGS__; } break;  \
+    case 1320: { constexpr int MM = 20, LR = 13; __VA_ARGS__; } break;  \
+    case 1322: { constexpr int MM = 22, LR = 13; __VA_ARGS__; } break;  \
     case 1324: { constexpr int MM = 24, LR = 13; __VA_ARGS__; } break;  \
     case 1332: { constexpr int MM = 32, LR = 13; __VA_ARGS__; } break;  \
     case 1348: { constexpr int MM = 48, LR = 13; __VA_ARGS__; } break;  \
     case 1212: { constexpr int MM = 12, LR = 12; __VA_ARGS__; } break;  \
     case 1216: { constexpr int MM = 16, LR = 12; __VA_ARGS__; } break;  \
+    case 1218: { constexpr int MM = 18, LR = 12; __VA_ARGS__; } break;  \
+    case 1220: { constexpr int MM = 20, LR = 12; __VA_ARGS__; } break;  \
+    case 1222: { constexpr int MM = 22, LR = 12; __VA_ARGS__; } break;  \
     case 1224: { constexpr int MM = 24, LR = 12; __VA_ARGS__; } break;  \
     case 1232: { constexpr int MM = 32, LR = 12; __VA_ARGS__; } break;  \
     case 1248: { constexpr int MM = 48, LR = 12; __VA_ARGS__; } break;  \

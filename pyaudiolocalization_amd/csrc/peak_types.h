@@ -60,8 +60,8 @@ struct PeakArgs {
   int local_pivots;                      // 1: fused column pass - no RowPre, no bracket lists: every segment brought a histogram
                                          //    window (BlockHist) and its own bound for untested samples (Partial.pfloor)
   BlockHist* bh;                         // [rows][splits] (local_pivots only)
-  int cols_per_block;                    // columns of the grid one segment covers (local_pivots only: 62, or 248 for short column DFTs)
-  int edge_n2;                           // > 0: segments are column blocks of the prime-factor grid (row length edge_n2);
+  int edge_n2;                           // > 0: segments are column blocks of the prime-factor grid (row length edge_n2; block q holds the
+                                         //      columns [q n2 / splits, (q + 1) n2 / splits));
                                          //      the finish launch tests the samples of columns 0 and edge_n2 - 1 itself
   RowPre* pre;                           // [rows]
   Partial* parts;                        // [rows][splits]

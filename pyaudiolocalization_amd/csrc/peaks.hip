@@ -984,7 +984,7 @@ __global__ __launch_bounds__(kT, 4) void k_peak_finish(PeakArgs a, pal_pair_reco
       for (int q = 0; q < S && N2 > 0; ++q) {
         const double pf = staged ? sparts[q].pfloor : a.parts[size_t(row) * S + q].pfloor;
         if (!(pf > -INFINITY) || (mb >= 0 && hb >= pf)) continue;          // (uniform)
-        const int c0 = q * a.cols_per_block, cols = N2 - c0 < a.cols_per_block ? N2 - c0 : a.cols_per_block;
+        const int c0 = int((long long)q * N2 / S), cols = int((long long)(q + 1) * N2 / S) - c0;   // (the columns are dealt evenly)
         eh = 0;
         em = -1;
         for (int k = tid; k < cols * N1; k += kT) test(c0 + k % cols + N2 * (k / cols), eh, em);
@@ -1257,7 +1257,6 @@ int Engine::peaks_setup(const double* corr, size_t stride, int rows, int n, int 
   a.snr_w = w > 1 ? w : 1;
   a.edge_n2 = blocks > 0 ? grid_n2 : 0;
   a.local_pivots = blocks > 0 ? 1 : 0;
-  a.cols_per_block = 62;
   a.stamps = nullptr;
   if (blocks > 0) {
     a.splits = blocks;

@@ -332,7 +332,6 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
   const int nblk = (f.n2 + per_blk - 1) / per_blk;
   PeakArgs a;
   PAL_TRY(peaks_setup(corr, stride, rows, pl.n, n2, prm, nblk, f.n2, on, a));
-  a.cols_per_block = per_blk;
   PAL_TRY(pfa_rows(pl, permuted, quads, G, Y, on));
   {
     ProfScope ps(this, "k_pfa_cols_stats", on);

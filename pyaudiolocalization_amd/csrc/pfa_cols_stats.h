@@ -7,7 +7,7 @@
 // (utils.py:145).  Here the values meet those statistics in the registers they were accumulated in, and the 0.7 MB per
 // row are only written (the finish launch still reads the few thousand samples around the peaks it resolves).
 //
-//   - a workgroup owns 62 columns m2 of one packed transform (both rows: pair p = real parts, pair q = imaginary
+//   - a workgroup owns up to 62 columns m2 (the grid's columns dealt evenly to the blocks) of one packed transform (both rows: pair p = real parts, pair q = imaginary
 //     parts) and all N1 output indices t, its four wavefronts four chunks of kPfaTC indices and their mirrors;
 //     lanes 0 and 63 compute the neighbouring blocks' border columns again, so that every owned sample has both
 //     neighbours m -/+ 1 = (m2 -/+ 1, t) one lane away (DPP wave shifts)
@@ -78,11 +78,16 @@ __global__ __launch_bounds__(64 * NW) void k_pfa_cols_stats(const cd* __restrict
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = STRIPS ? 0 : wave;                           // nch <= 4: one workgroup covers every output index
   const int g = blockIdx.x % G, cb = blockIdx.x / G;
-  const int strip = STRIPS ? cb * NW + wave : cb;             // 62-column strip of this wavefront
-  const bool active = STRIPS ? strip * kColsOwn < N2 : ch < nch;
-  const int m2 = strip * kColsOwn - 1 + lane;
-  const bool live = m2 >= 0 && m2 < N2;
-  const bool own = live && lane >= 1 && lane <= kColsOwn;
+  const int strip = STRIPS ? cb * NW + wave : cb;             // column strip of this wavefront
+  // The grid's columns are dealt EVENLY to the strips (widths differ by one, at most kColsOwn): with fixed 62-column strips the
+  // last one can be a few columns wide (4219 = 68 x 62 + 3), and the median of so small a block lies so far from the row's
+  // that its 48-bin window misses it - the finish launch then needs the exact median of the row (18 % of the rows at 21 x 4219).
+  const int strips = int(gridDim.x / unsigned(G)) * (STRIPS ? NW : 1);
+  const int c_lo = int((long long)strip * N2 / strips), c_hi = int((long long)(strip + 1) * N2 / strips);   // owned columns [c_lo, c_hi)
+  const bool active = STRIPS ? true : ch < nch;
+  const int m2 = c_lo - 1 + lane;
+  const bool live = m2 >= 0 && m2 < N2 && lane <= c_hi - c_lo + 1;   // the owned columns and one border lane on each side
+  const bool own = live && lane >= 1 && lane <= c_hi - c_lo;
   const bool inner = own && m2 >= 1 && m2 <= N2 - 2;          // both neighbours are samples of the same output index
   const int m2c = m2 < 0 ? 0 : (m2 < N2 ? m2 : N2 - 1);       // border lanes outside the grid repeat its first / last column
   const cd* Yg = Y + size_t(g) * N1 * N2 + m2c;

@@ -12,6 +12,7 @@
 // no exchange, only a renaming of registers (BigTile::reg_of / slot_of).
 #pragma once
 #include "fft_core.h"
+#include "mixed_radix.h"
 
 namespace pal {
 
@@ -139,13 +140,16 @@ __device__ __forceinline__ cd uniform_root(const cd* roots, int m) {
 
 template <int N, bool INV>
 __device__ __forceinline__ void reg_dft(cd* v, const cd* roots) {
-  static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 3 || N == 6 || N == 12 || N == 24 || N == 48, "column length");
+  static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 3 || N == 6 || N == 12 || N == 24 || N == 48 ||
+                N == 18 || N == 20 || N == 22, "column length");
   if constexpr (N == 1) {
     return;
   } else if constexpr (N == 2 || N == 4 || N == 8 || N == 16) {
     dftR<N, INV>(v);
-  } else if constexpr (N == 32) {
-    constexpr int P = 16;
+  } else if constexpr (N == 32 || N == 18 || N == 20 || N == 22) {
+    // N = 2 P: X[2k] = DFT_P(x[e] + x[P + e]), X[2k + 1] = DFT_P((x[e] - x[P + e]) exp(-/+ 2 pi i e / N)); P = 16, or 9 / 10 / 11
+    // on the real-symmetric butterflies of the Rader row pass (mixed_radix.h)
+    constexpr int P = N / 2;
     cd y[2][P];
 #pragma unroll
     for (int e = 0; e < P; ++e) {
@@ -154,8 +158,13 @@ __device__ __forceinline__ void reg_dft(cd* v, const cd* roots) {
       const cd w = uniform_root(roots, e);
       y[1][e] = e == 0 ? d : (INV ? cmulc(d, w) : cmul(d, w));
     }
-    dftR<P, INV>(y[0]);
-    dftR<P, INV>(y[1]);
+    if constexpr (P == 16) {
+      dftR<P, INV>(y[0]);
+      dftR<P, INV>(y[1]);
+    } else {
+      dft_sym<P, INV>(y[0]);
+      dft_sym<P, INV>(y[1]);
+    }
 #pragma unroll
     for (int k = 0; k < P; ++k) { v[2 * k] = y[0][k]; v[2 * k + 1] = y[1][k]; }
   } else {

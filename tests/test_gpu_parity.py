@@ -161,6 +161,39 @@ def test_prime_factor_route_odd_pair_counts_and_tables(engine, monkeypatch):
 
 # frame lengths whose split has N1 <= 89: there the column pass of the prime-factor route also does the streaming pass of
 # the peak selection, every column block with its own pivots (pfa_cols_stats.h; PAL_FUSED=0 keeps the separate launches)
+# convolution geometries of the four-step route with register-resident rows (conv_kernels.h k_colsreg_* / k_rowsreg): frame
+# length -> (columns, row length) of the PHAT inverse's convolution; the LDS-tile passes (PAL_FOUR_REG=0) are the independent route
+REG_GEOMETRIES = [(12000, 12, 4096), (16000, 16, 4096), (18000, 18, 4096), (20000, 20, 4096), (22000, 22, 4096), (24000, 24, 4096),
+                  (30000, 16, 8192), (36000, 18, 8192), (40500, 20, 8192), (44102, 22, 8192), (48001, 24, 8192)]
+
+
+@pytest.mark.parametrize("length,m1,m2", REG_GEOMETRIES)
+def test_register_row_four_step_matches_lds_tiles_and_numpy(length, m1, m2, monkeypatch):
+    """Both four-step cuts must reproduce numpy's exact-length transforms to rounding and select the same peaks; the
+    prime-factor route is off in both engines so that the PHAT inverse really runs the convolution under test."""
+    from pyaudiolocalization_amd import Engine
+    monkeypatch.setenv("PAL_PFA", "0")
+    reg = Engine(0)
+    monkeypatch.setenv("PAL_FOUR_REG", "0")
+    lds = Engine(0)
+    try:
+        info = reg.plan_info(length)
+        assert (info["m1"], info["m2"]) == (m1, m2) and info["n1"] == 0, info
+        assert lds.plan_info(length)["m2"] <= 2048
+        rng = np.random.default_rng(length)
+        frames = rng.standard_normal((1, 4, length))
+        frames[0, 1:] += 0.6 * np.roll(frames[0, :1], 37, axis=1)
+        t1, c1 = reg.gcc_phat_all_pairs(frames, 16000.0, want_corr=True)
+        t0, c0 = lds.gcc_phat_all_pairs(frames, 16000.0, want_corr=True)
+        assert np.array_equal(t1["k_sel"], t0["k_sel"]) and np.array_equal(t1["branch"], t0["branch"])
+        assert np.max(np.abs(c1 - c0)) <= 1e-13
+        want = O.phat_correlation(frames[0, 0], frames[0, 1])
+        assert np.max(np.abs(c1[0, 0] - want)) <= 1e-13
+    finally:
+        reg.close()
+        lds.close()
+
+
 FUSED_LENGTHS = [(11962, 47, 509), (15525, 61, 509), (22651, 89, 509), (44100, 89, 991), (7890, 31, 509), (1008, 5, 403),
                  (10233, 5, 4093), (24000, 7, 6857)]
 
@@ -642,7 +675,7 @@ def test_localize_from_audio_files(engine, tmp_path):
 
 def test_profile_counters_and_plan(engine):
     info = engine.plan_info(44100)
-    assert info["n"] == 88199 and info["conv_len"] in (196608, 262144) and info["m1"] * info["m2"] == info["conv_len"]
+    assert info["n"] == 88199 and info["conv_len"] in (180224, 196608, 262144) and info["m1"] * info["m2"] == info["conv_len"]
     frames = np.random.default_rng(0).standard_normal((1, 4, 2000))
     engine.profile_begin()
     engine.gcc_phat_all_pairs(frames, 16000.0)
