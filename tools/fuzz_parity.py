@@ -15,6 +15,7 @@ bad = ties = rows = 0
 t0 = time.time()
 for case in range(cases):
     L = int(rng.choice([rng.integers(2, 64), rng.integers(64, 700), rng.integers(700, 3000), rng.integers(3000, 9000),
+                        rng.integers(9000, 25000), rng.integers(25000, 49000),   # register row tiles, register-row four-step geometries
                         rng.choice([496, 11962, 15525, 22651, 44100])]))   # (Rader rows at 991 = 2 x 496 - 1, fused column pass where the plan has N1 <= 89)
     mics = int(rng.integers(2, 7))
     fs = float(rng.choice([8000.0, 16000.0, 44100.0, 48000.0]))
