@@ -287,7 +287,7 @@ int Engine::alloc_conv(Conv& c, size_t needed) {
       if ((four_reg == 12 || four_reg == 13) && lr != four_reg) continue;
       for (int m1 : kCols) {
         if (lr == 12 && m1 < 12) continue;
-        if (m1 > 24 && four_reg < 0) continue;
+        if (m1 > 24 && (lr != 13 || four_reg == 0)) continue;      // 32- / 48-point columns: two lanes per column, rows of 8192
         const size_t m = size_t(m1) << lr;
         if (m < needed || m > c.m) continue;               // (never longer than the 2^k / 3 * 2^k choice)
         if (!best_m || m < best_m) { best_m = m; best_lr = lr; best_m1 = m1; }   // ties: the shorter rows (lr = 12 comes first)

@@ -327,6 +327,89 @@ __global__ __launch_bounds__(kRegCols) void k_colsreg_inv(const cd* __restrict__
   for (int r = 0; r < M1; ++r) st(g, (unsigned(r) << kRegL2) + c, v[r]);
 }
 
+// Columns of 32 or 48 points (C4: 393 216 = 48 x 8192) need 250 registers in one lane; here TWO neighbouring lanes share a
+// column: lane `half` holds the rows 2 j + half on the time side and the rows k + half * M1 / 2 on the frequency side, each
+// lane transforms its M1 / 2 points (reg_dft) and ONE exchange with the partner lane (DPP quad_perm [1,0,3,2], one move per
+// dword) completes the radix-2 step:  X[k], X[k + M1/2] = E[k] +/- w^k O[k]  (forward);
+// x[2 j + p] = IDFT_{M1/2}((X[k] +/- X[k + M1/2]) w^(-p k))[j]  (inverse).  128 columns per workgroup: a wavefront's load or
+// store is two contiguous 512-byte requests.
+__device__ __forceinline__ double from_partner_lane(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xf, 0xf, true);            // quad_perm:[1,0,3,2]
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ cd from_partner_lane(cd v) { return mk(from_partner_lane(v.x), from_partner_lane(v.y)); }
+
+// four-step twiddle of the rows k0 + k, k < MH, of column c (k0 = 0 or MH, a multiple of 4): see colsreg_twiddle
+template <int MH, int kRegL2, bool INV>
+__device__ __forceinline__ void colsreg_twiddle_from(cd* v, unsigned c, int k0, const cd* __restrict__ twA, const cd* __restrict__ twB) {
+  static_assert(MH % 4 == 0, "anchors every fourth row");
+  const cd w1 = twB[c];
+  const cd w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+#pragma unroll
+  for (int k = 0; k < MH; ++k) {
+    cd w;
+    if ((k & 3) == 0) {
+      w = four_step_twiddle(c * unsigned(k0 + k), kRegL2, twA, twB);        // (row 0: twA[0] twB[0] = 1 exactly)
+    } else {
+      const cd anchor = four_step_twiddle(c * unsigned(k0 + (k & ~3)), kRegL2, twA, twB);
+      w = cmul(anchor, (k & 3) == 1 ? w1 : ((k & 3) == 2 ? w2 : w3));
+    }
+    v[k] = INV ? cmulc(v[k], w) : cmul(v[k], w);
+  }
+}
+
+template <int M1, int kRegL2, class Loader>
+__global__ __launch_bounds__(kRegCols) void k_colsreg2_fwd(Loader ld, cd* __restrict__ W, int G, const cd* __restrict__ twA,
+                                                           const cd* __restrict__ twB, int xcd) {
+  constexpr int MH = M1 / 2, COLS = kRegCols / 2;
+  int g, tile;
+  if (!row_work_item(blockIdx.x, G, (1 << kRegL2) / COLS, xcd, g, tile)) return;
+  const int half = threadIdx.x & 1;
+  const unsigned c = unsigned(tile) * COLS + (threadIdx.x >> 1);
+  cd v[MH];
+#pragma unroll
+  for (int j = 0; j < MH; ++j) v[j] = ld(g, (unsigned(2 * j + half) << kRegL2) + c);
+  reg_dft<MH, false, 2>(v, twA);                               // E (half 0) or O (half 1)
+#pragma unroll
+  for (int k = 0; k < MH; ++k) {
+    const cd w = uniform_root(twA, k);
+    const cd mine = (half && k) ? cmul(v[k], w) : v[k];        // O[k] w^k on the odd lane
+    const cd theirs = from_partner_lane(mine);
+    v[k] = half ? theirs - mine : mine + theirs;               // X[k] = E + P on the even lane, X[k + MH] = E - P on the odd one
+  }
+  colsreg_twiddle_from<MH, kRegL2, false>(v, c, half * MH, twA, twB);
+  cd* out = W + (size_t(g) * M1 << kRegL2) + c + (size_t(half * MH) << kRegL2);
+#pragma unroll
+  for (int k = 0; k < MH; ++k) out[size_t(k) << kRegL2] = v[k];
+}
+
+template <int M1, int kRegL2, class Storer>
+__global__ __launch_bounds__(kRegCols) void k_colsreg2_inv(const cd* __restrict__ W, Storer st, int G, const cd* __restrict__ twA,
+                                                           const cd* __restrict__ twB, int xcd) {
+  constexpr int MH = M1 / 2, COLS = kRegCols / 2;
+  int g, tile;
+  if (!row_work_item(blockIdx.x, G, (1 << kRegL2) / COLS, xcd, g, tile)) return;
+  const int half = threadIdx.x & 1;
+  const unsigned c = unsigned(tile) * COLS + (threadIdx.x >> 1);
+  const cd* in = W + (size_t(g) * M1 << kRegL2) + c + (size_t(half * MH) << kRegL2);
+  cd v[MH];
+#pragma unroll
+  for (int k = 0; k < MH; ++k) v[k] = in[size_t(k) << kRegL2];
+  colsreg_twiddle_from<MH, kRegL2, true>(v, c, half * MH, twA, twB);
+#pragma unroll
+  for (int k = 0; k < MH; ++k) {
+    const cd theirs = from_partner_lane(v[k]);
+    const cd w = uniform_root(twA, k);
+    const cd dif = theirs - v[k];                              // odd lane: X[k] - X[k + MH]
+    v[k] = half ? (k ? cmulc(dif, w) : dif) : v[k] + theirs;
+  }
+  reg_dft<MH, true, 2>(v, twA);
+#pragma unroll
+  for (int j = 0; j < MH; ++j) st(g, (unsigned(2 * j + half) << kRegL2) + c, v[j]);
+}
+
 // rows of 8192 points: one workgroup per row.  CONV: forward, x chirp spectrum, inverse, in place; else forward x scale.
 template <int kRegL2, bool CONV>
 __global__ __launch_bounds__((BigTile<kRegL2, 32>::kLanes)) __attribute__((amdgpu_waves_per_eu(2)))
@@ -381,16 +464,12 @@ void k_rowsreg(cd* __restrict__ W, const cd* __restrict__ chat, int rows, int G,
     case 1320: { constexpr int MM = 20, LR = 13; __VA_ARGS__; } break;  \
     case 1322: { constexpr int MM = 22, LR = 13; __VA_ARGS__; } break;  \
     case 1324: { constexpr int MM = 24, LR = 13; __VA_ARGS__; } break;  \
-    case 1332: { constexpr int MM = 32, LR = 13; __VA_ARGS__; } break;  \
-    case 1348: { constexpr int MM = 48, LR = 13; __VA_ARGS__; } break;  \
     case 1212: { constexpr int MM = 12, LR = 12; __VA_ARGS__; } break;  \
     case 1216: { constexpr int MM = 16, LR = 12; __VA_ARGS__; } break;  \
     case 1218: { constexpr int MM = 18, LR = 12; __VA_ARGS__; } break;  \
     case 1220: { constexpr int MM = 20, LR = 12; __VA_ARGS__; } break;  \
     case 1222: { constexpr int MM = 22, LR = 12; __VA_ARGS__; } break;  \
     case 1224: { constexpr int MM = 24, LR = 12; __VA_ARGS__; } break;  \
-    case 1232: { constexpr int MM = 32, LR = 12; __VA_ARGS__; } break;  \
-    case 1248: { constexpr int MM = 48, LR = 12; __VA_ARGS__; } break;  \
     default: return e->fail(PAL_ERR_INTERNAL, "register column pass of %d points, rows of 2^%d", m1, l2); \
   }
 
@@ -425,7 +504,13 @@ static int launch_cols_fwd(Engine* e, const Conv& c, int G, Loader ld, cd* W, hi
   ProfScope ps(e, name, on);
   if (c.reg) {
     const int xcd = e->xcd_rows && G > 1;
-    const unsigned grid = row_work_grid(G, (1 << c.l2) / kRegCols, xcd);
+    const bool pair = c.M1() > 24;                             // two lanes per column
+    const unsigned grid = row_work_grid(G, (1 << c.l2) / (pair ? kRegCols / 2 : kRegCols), xcd);
+    if (pair) {
+      if (c.M1() == 48) k_colsreg2_fwd<48, 13, Loader><<<dim3(grid), dim3(kRegCols), 0, on>>>(ld, W, G, c.twA, c.twB, xcd);
+      else if (c.M1() == 32) k_colsreg2_fwd<32, 13, Loader><<<dim3(grid), dim3(kRegCols), 0, on>>>(ld, W, G, c.twA, c.twB, xcd);
+      else return e->fail(PAL_ERR_INTERNAL, "two-lane column pass of %d points", c.M1());
+    } else
     PAL_SWITCH_M1(c.M1(), c.l2, k_colsreg_fwd<MM, LR, Loader><<<dim3(grid), dim3(kRegCols), 0, on>>>(ld, W, G, c.twA, c.twB, xcd));
   } else if (c.r3) {
     const int tiles = int(c.M() / kPoints3), xcd = e->xcd_rows && G > 1;
@@ -476,7 +561,13 @@ static int launch_cols_inv(Engine* e, const Conv& c, int G, const cd* W, Storer 
   ProfScope ps(e, name, on);
   if (c.reg) {
     const int xcd = e->xcd_rows && G > 1;
-    const unsigned grid = row_work_grid(G, (1 << c.l2) / kRegCols, xcd);
+    const bool pair = c.M1() > 24;                             // two lanes per column
+    const unsigned grid = row_work_grid(G, (1 << c.l2) / (pair ? kRegCols / 2 : kRegCols), xcd);
+    if (pair) {
+      if (c.M1() == 48) k_colsreg2_inv<48, 13, Storer><<<dim3(grid), dim3(kRegCols), 0, on>>>(W, st, G, c.twA, c.twB, xcd);
+      else if (c.M1() == 32) k_colsreg2_inv<32, 13, Storer><<<dim3(grid), dim3(kRegCols), 0, on>>>(W, st, G, c.twA, c.twB, xcd);
+      else return e->fail(PAL_ERR_INTERNAL, "two-lane column pass of %d points", c.M1());
+    } else
     PAL_SWITCH_M1(c.M1(), c.l2, k_colsreg_inv<MM, LR, Storer><<<dim3(grid), dim3(kRegCols), 0, on>>>(W, st, G, c.twA, c.twB, xcd));
   } else if (c.r3) {
     const unsigned grid = unsigned(size_t(G) * (c.M() / kPoints3));

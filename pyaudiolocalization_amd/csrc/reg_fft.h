@@ -138,7 +138,7 @@ __device__ __forceinline__ cd uniform_root(const cd* roots, int m) {
   return mk(p[0], p[1]);
 }
 
-template <int N, bool INV>
+template <int N, bool INV, int STRIDE = 1>   // roots[m * STRIDE] = exp(-2 pi i m / N): a table of N * STRIDE roots serves every divisor
 __device__ __forceinline__ void reg_dft(cd* v, const cd* roots) {
   static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 3 || N == 6 || N == 12 || N == 24 || N == 48 ||
                 N == 18 || N == 20 || N == 22, "column length");
@@ -155,7 +155,7 @@ __device__ __forceinline__ void reg_dft(cd* v, const cd* roots) {
     for (int e = 0; e < P; ++e) {
       y[0][e] = v[e] + v[P + e];
       const cd d = v[e] - v[P + e];
-      const cd w = uniform_root(roots, e);
+      const cd w = uniform_root(roots, e * STRIDE);
       y[1][e] = e == 0 ? d : (INV ? cmulc(d, w) : cmul(d, w));
     }
     if constexpr (P == 16) {
@@ -180,7 +180,7 @@ __device__ __forceinline__ void reg_dft(cd* v, const cd* roots) {
       y[0][e] = a0 + sum;
       cd y1 = mid + rot, y2 = mid - rot;
       if (e > 0) {
-        const cd w1 = uniform_root(roots, e), w2 = uniform_root(roots, 2 * e);
+        const cd w1 = uniform_root(roots, e * STRIDE), w2 = uniform_root(roots, 2 * e * STRIDE);
         y1 = INV ? cmulc(y1, w1) : cmul(y1, w1);
         y2 = INV ? cmulc(y2, w2) : cmul(y2, w2);
       }

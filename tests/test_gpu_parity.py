@@ -164,7 +164,9 @@ def test_prime_factor_route_odd_pair_counts_and_tables(engine, monkeypatch):
 # convolution geometries of the four-step route with register-resident rows (conv_kernels.h k_colsreg_* / k_rowsreg): frame
 # length -> (columns, row length) of the PHAT inverse's convolution; the LDS-tile passes (PAL_FOUR_REG=0) are the independent route
 REG_GEOMETRIES = [(12000, 12, 4096), (16000, 16, 4096), (18000, 18, 4096), (20000, 20, 4096), (22000, 22, 4096), (24000, 24, 4096),
-                  (30000, 16, 8192), (36000, 18, 8192), (40500, 20, 8192), (44102, 22, 8192), (48001, 24, 8192)]
+                  (30000, 16, 8192), (36000, 18, 8192), (40500, 20, 8192), (44102, 22, 8192), (48001, 24, 8192),
+                  # two lanes per column
+                  (60000, 32, 8192), (90000, 48, 8192)]
 
 
 @pytest.mark.parametrize("length,m1,m2", REG_GEOMETRIES)
