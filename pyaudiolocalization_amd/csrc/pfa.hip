@@ -72,6 +72,7 @@ void Engine::free_pfa(Pfa& f) {
 
 #define PAL_SWITCH_LM(lm, ...)                                     \
   switch (lm) {                                                    \
+    case 9: { constexpr int LM = 9; __VA_ARGS__; } break;          \
     case 10: { constexpr int LM = 10; __VA_ARGS__; } break;        \
     case 11: { constexpr int LM = 11; __VA_ARGS__; } break;        \
     case 12: { constexpr int LM = 12; __VA_ARGS__; } break;        \
@@ -89,14 +90,14 @@ int Engine::build_pfa(Plan& pl) {
   // traffic plus 4e-8 N1 n for the dense N1-point DFTs.  The four-step route: 1.6e-5 per point of its convolution for the
   // first two passes, 2.2e-5 n for the last pass and the statistics launches, x 0.86 with register-resident rows.  A split that cannot take the fused column
   // pass (more than four chunks of output indices: N1 > 89) must beat the four-step route by 15 %.
-  static const double kTile[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.005, 0.0113, 0.026, 0.050, 0.145};
+  static const double kTile[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0.003, 0.005, 0.0113, 0.026, 0.050, 0.145};
   double best = -1;
   int bn1 = 0, bn2 = 0, blm = 0;
   for (long long d = 1; d <= 127 && d <= n; d += 2) {
     if (n % d) continue;
     const long long r = n / d;
     if (r > (allow_big ? 8192 : 2048) || gcd_ll(d, r) != 1) continue;
-    int lm = 10;
+    int lm = 9;
     while ((1ll << lm) < 2 * r - 1) ++lm;
     const int chunks = d > 1 ? int(((d - 1) / 2 + kPfaTC - 1) / kPfaTC) : 1;
     double cost = double(d) * kTile[lm] + double(n) * (1.15e-5 + 4e-8 * double(d));

@@ -212,7 +212,9 @@ __global__ __launch_bounds__(PfaLds<LM>::kLanes) void k_pfa_rows(PfaRowsArgs a) 
   {
     cd* const Yg = a.Y + size_t(g) * a.N1 * a.N2;
     const int N1 = a.N1, N2 = a.N2;
-    const int t = __builtin_amdgcn_readfirstlane(ts);         // tile: wave-uniform (NB lanes = whole wavefronts)
+    // tile: wave-uniform where NB lanes are whole wavefronts; at 512 points a wavefront holds both tiles (per-lane values,
+    // vector loads of the row table)
+    const int t = NB >= 64 ? __builtin_amdgcn_readfirstlane(ts) : ts;
     const int row = t ? (k1 ? N1 - k1 : 0) : k1;
     // chirp and column-twiddle factors of this lane's outputs: requested before the inverse middle stages, which touch
     // only LDS, so that they have landed when the last stage needs them

@@ -38,10 +38,12 @@ def test_phat_correlation_matches_numpy(engine, n1, n2):
 # frame lengths whose n = 2L-1 exercises every shape of the prime-factor route (pfa.hip): one row tile
 # (99 = 1 x 99, 999 = 1 x 999; 991 = 1 x 991 and 88199 = 89 x 991 take the Rader row pass of pfa_rader.h), dense column DFTs with N1 = 9 / 7 / 3 / 11 / 89, tiles of 1024 / 2048 / 4096 points,
 # and lengths that have no usable split (1999 prime) and stay on the four-step chirp convolution
-PFA_LENGTHS = [(50, 1, 99, 1024), (496, 1, 991, 990), (500, 1, 999, 2048), (1000, 0, 0, 0), (2048, 9, 455, 1024), (2999, 3, 1999, 4096),
+PFA_LENGTHS = [(50, 1, 99, 512), (496, 1, 991, 990), (500, 1, 999, 2048), (1000, 0, 0, 0), (2048, 9, 455, 1024), (2999, 3, 1999, 4096),
                (3000, 7, 857, 2048), (5000, 11, 909, 2048), (44100, 89, 991, 990),
                # register-resident row tiles (pfa_big.h): 8192 points at 20465 = 5 x 4093, 16384 points at C3's 47999 = 7 x 6857
-               (10233, 5, 4093, 8192), (24000, 7, 6857, 16384)]
+               (10233, 5, 4093, 8192), (24000, 7, 6857, 16384),
+               # 512-point LDS tiles (N2 <= 256): C5's 23999 = 103 x 233
+               (12000, 103, 233, 512), (11170, 89, 251, 512)]
 
 
 @pytest.mark.parametrize("length,n1,n2,tile", PFA_LENGTHS)
@@ -197,7 +199,9 @@ def test_register_row_four_step_matches_lds_tiles_and_numpy(length, m1, m2, monk
 
 
 FUSED_LENGTHS = [(11962, 47, 509), (15525, 61, 509), (22651, 89, 509), (44100, 89, 991), (7890, 31, 509), (1008, 5, 403),
-                 (10233, 5, 4093), (24000, 7, 6857)]
+                 (10233, 5, 4093), (24000, 7, 6857),
+                 # 512-point row tiles under the fused column pass: 22339 = 89 x 251
+                 (11170, 89, 251)]
 
 
 def _plan_of(engine, length):
