@@ -99,6 +99,10 @@ int Engine::build_pfa(Plan& pl) {
     if (r > (allow_big ? 8192 : 2048) || gcd_ll(d, r) != 1) continue;
     int lm = 9;
     while ((1ll << lm) < 2 * r - 1) ++lm;
+    // (16384-point tiles run one workgroup per CU for 45 us each: with few rows per transform the rounds of workgroups and the
+    //  per-group fixed costs weigh more than the model says - 24 051 = 3 x 8017 measured 1.41 M pairs/s against 1.84 M on the
+    //  four-step route, 48 k-point lengths break even: profiles/r02_g_length_sweep_*.csv)
+    if (lm == 14 && n < 40000) continue;
     const int chunks = d > 1 ? int(((d - 1) / 2 + kPfaTC - 1) / kPfaTC) : 1;
     double cost = double(d) * kTile[lm] + double(n) * (1.15e-5 + 4e-8 * double(d));
     if (chunks > 4) cost *= 1.15;
