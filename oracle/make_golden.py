@@ -180,14 +180,15 @@ def golden_c5(frames=(0, 1)):
     save("c5_stream_frames01.npz", **out)
 
 
-def golden_metric(mics=8):
+def golden_metric(mics=24):
+    """first 24 microphones of frame 0 of the metric workload: the 276 pairs bench.py checks inside every run"""
     frames = cases.metric_frames(1, mics)[0]
     out = {}
     for med in (0.05, None):
         tag = "none" if med is None else "0p05"
         for k, v in pair_table(list(frames), 44100, med).items():
             out[f"{k}_{tag}"] = v
-    save("metric_44k1_first8.npz", **out)
+    save("metric_44k1_first24.npz", **out)
 
 
 def golden_selection_edges():
@@ -275,9 +276,56 @@ def golden_localize_extras():
     save("localize_extras.npz", **out)
 
 
+def golden_sensitivity():
+    """The reference against ITSELF: main.py:165-298 with the simulated signals of C1 / C2a / C2b / C3 moved by one unit in the
+    last place (every sample to its neighbouring double, direction drawn from default_rng(77)).  The Butterworth prefilter
+    (signal_processing.py:127-128) amplifies that, PHAT whitening promotes it: the fraction of selected indices that
+    change and the distance the estimated position moves are the reference's OWN spread - the bound an implementation
+    whose simulated signals are not bit-identical to the reference's can be held to (tests/test_gpu_localize.py)."""
+    out = {}
+    todo = [("c1", cases.c1_config(), None, None, "c1_example1.npz", ""),
+            ("c2a", cases.c2_config(), None, None, "c2_chirp8.npz", "a_"),
+            ("c2b", cases.c2_config(), cases.LOW_LOSS, None, "c2_chirp8.npz", "b_"),
+            ("c3", cases.c3_config(0), None, cases.c3_base(0), "c3_grid64_trial0.npz", "")]
+    keep_sim = ref_main.simulate_signals_with_multipath
+    for tag, cfg, table, base, fixture, prefix in todo:
+        gold = np.load(os.path.join(OUT, fixture))
+        rng = np.random.default_rng(77)
+
+        def nudged(*a, **k):
+            sig = keep_sim(*a, **k)
+            return [np.nextafter(x, np.where(rng.integers(0, 2, x.size) > 0, np.inf, -np.inf)) for x in sig]
+
+        keep_mat, keep_gen = ref_main.material_properties, ref_sp.generate_signal
+        try:
+            if table is not None:
+                ref_main.material_properties = table
+            if base is not None:
+                ref_sp.generate_signal = lambda *a, **k: base.copy()
+            sig = nudged(cfg["source_position"], np.array(cfg["mic_positions"]), cfg["fs"], cases.C_SOUND, cfg["duration"],
+                         cfg["signal_type"], cfg["freq"], cfg["reflective_planes"], ref_main.material_properties, 3, 0.01)
+        finally:
+            ref_main.material_properties, ref_sp.generate_signal = keep_mat, keep_gen
+        st = stage_outputs(sig, cfg["fs"], (0.05,))
+        k0, k1 = gold[prefix + "k_sel_0p05"], st["k_sel_0p05"]
+        out[tag + "_rows"] = np.array([k0.size])
+        out[tag + "_rows_differ"] = np.array([int(np.count_nonzero(k0 != k1))])
+        out[tag + "_k_sel_nudged"] = k1
+        rng = np.random.default_rng(77)                     # the same nudge inside localize_sound_source
+        ref_main.simulate_signals_with_multipath = nudged
+        try:
+            pos = run_localize(cfg, materials=table, base=base)
+        finally:
+            ref_main.simulate_signals_with_multipath = keep_sim
+        out[tag + "_position_nudged"] = pos
+        out[tag + "_position_delta_m"] = np.array([float(np.linalg.norm(pos - gold[prefix + "position"]))])
+        print(f"  {tag}: {out[tag + '_rows_differ'][0]}/{k0.size} selected indices change, position moves {out[tag + '_position_delta_m'][0]:.3e} m", flush=True)
+    save("sensitivity.npz", **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["edges", "filters", "images", "c1", "c2", "metric", "c4", "c5", "c3", "calibration", "extras"]
-    table = {"extras": golden_localize_extras, "calibration": golden_calibration, "edges": golden_selection_edges, "filters": golden_filters, "images": golden_images, "c1": golden_c1,
+    todo = sys.argv[1:] or ["edges", "filters", "images", "c1", "c2", "metric", "c4", "c5", "c3", "calibration", "extras", "sensitivity"]
+    table = {"sensitivity": golden_sensitivity, "extras": golden_localize_extras, "calibration": golden_calibration, "edges": golden_selection_edges, "filters": golden_filters, "images": golden_images, "c1": golden_c1,
              "c2": golden_c2, "c3": golden_c3, "c4": golden_c4, "c5": golden_c5, "metric": golden_metric}
     for key in todo:
         t0 = time.time()

@@ -122,10 +122,10 @@ def test_c5_stream_frames(golden):
         stages.run_chain(IMPL, g, f"f{f}_", *stages.c5_case(f), (0.05,), pair_idx=np.arange(0, 2016, 41))
 
 
-def test_metric_frames_first8(golden):
-    g = golden("metric_44k1_first8.npz")
-    frames = cases.metric_frames(1, 8)[0]
-    idx = np.arange(0, 28, 2)
+def test_metric_frames_first24(golden):
+    g = golden("metric_44k1_first24.npz")
+    frames = cases.metric_frames(1, 24)[0]
+    idx = np.arange(0, 276, 12)
     for med in (0.05, None):
         check_table(IMPL.pair_table(frames, 44100, med, idx), g, tag_of(med), idx, exact_values=True)
 
