@@ -225,6 +225,52 @@ __global__ __launch_bounds__(256) void k_pair_zero(const int4* __restrict__ quad
   zero_rows[2 * g + 1] = q.z >= 0 && (!nonzero[q.z] || !nonzero[q.w]);
 }
 
+// ---- the pairs the finishing column pass flagged (pfa_cols_fin.h), in pair order: list, packed pair table, scatter ----
+// one workgroup walks the flags in tiles of 1024 (a stable compaction: the packing of the flagged pairs, and with it the
+// last bits of their records, does not depend on the order in which the launch groups finished)
+__global__ __launch_bounds__(1024) void k_flag_list(const int* __restrict__ need, int64_t npairs, int* __restrict__ list, int* __restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int64_t p0 = 0; p0 < npairs; p0 += 1024) {
+    const int64_t p = p0 + tid;
+    const bool f = p < npairs && need[p] != 0;
+    const unsigned long long mask = __ballot(f);
+    if (lane == 0) wsum[wave] = __popcll(mask);
+    __syncthreads();
+    int before = base;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (f) list[before + __popcll(mask & ((1ull << lane) - 1ull))] = int(p);
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base += t; }
+    __syncthreads();
+  }
+  if (tid == 0) *count = base;
+}
+
+__global__ __launch_bounds__(256) void k_flag_quads(const int4* __restrict__ quads, const int* __restrict__ list, int count, int4* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (count + 1) / 2) return;
+  int v[4] = {0, 0, -1, -1};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (2 * i + h >= count) break;
+    const int p = list[2 * i + h];
+    const int4 q = quads[p >> 1];
+    v[2 * h] = p & 1 ? q.z : q.x;
+    v[2 * h + 1] = p & 1 ? q.w : q.y;
+  }
+  out[i] = make_int4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ __launch_bounds__(256) void k_flag_scatter(const pal_pair_record* __restrict__ src, const int* __restrict__ list, int count,
+                                                      pal_pair_record* __restrict__ table) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < count) table[list[i]] = src[i];
+}
+
 // ------------------------------------------------------------------ plans
 const cd* Engine::stage_table(int ln) {
   if (!stage_tw[ln]) {
@@ -512,6 +558,14 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     k_pair_zero<<<dim3(unsigned((ntr + 255) / 256)), dim3(256), 0, stream>>>(quads, nonzero, ntr, zero_rows);
     PAL_HIP(hipGetLastError());
   }
+  // the finishing column pass (pfa_cols_fin.h) writes one flag per pair: 1 = resolved at the end of this call from stored rows
+  const bool fin = pfa && table && !split && pfa_sub == 0 && !corr_out && !ksel_multi && pfa_can_fuse(pl) && pfa_can_finish(pl, prm);
+  int* need = nullptr;
+  if (fin) {
+    void* np = nullptr;
+    PAL_TRY(scratch(19, (size_t(2 * npairs) + 64) * sizeof(int), &np));     // [flags | list | count]
+    need = static_cast<int*>(np);
+  }
   if (two || split) {   // the other streams start after everything already queued on `stream` (spectra, pair table)
     PAL_HIP(hipEventRecord(ev_corr[0], stream));
     PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[0], 0));
@@ -531,7 +585,11 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     double* crow = via_scratch ? cbuf + size_t(slot) * buf_doubles : corr_out + size_t(p0) * stride;
     if (split && group >= 2) PAL_HIP(hipStreamWaitEvent(stream, ev_peaks[slot], 0));   // group - 2 is done with this buffer
     const bool fused = pfa && table && !split && pfa_sub == 0 && pfa_can_fuse(pl);
-    if (fused) {
+    if (fin) {
+      // nobody reads the correlation rows: the column pass finishes them without storing them (pfa_cols_fin.h)
+      PAL_TRY(pfa_pair_group_fin(pl, permuted, quads + t0, G, rows, Wg, zero_rows ? zero_rows + p0 : nullptr, prm, n2, table + p0, need + p0,
+                                 slot, on));
+    } else if (fused) {
       PAL_TRY(pfa_pair_group_fused(pl, permuted, quads + t0, G, rows, Wg, crow, stride, zero_rows ? zero_rows + p0 : nullptr, prm, n2, table + p0,
                                    ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr, on));
     } else if (pfa) {
@@ -586,6 +644,33 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     if (nslot == 3) {
       PAL_HIP(hipEventRecord(ev_join3, stream3));
       PAL_HIP(hipStreamWaitEvent(stream, ev_join3, 0));
+    }
+  }
+  if (fin) {
+    // The pairs the finishing blocks flagged (a threshold comparison inside the median's interval, a tie, a window peak next to
+    // the window's edge, ...) go through the stored-row path now, packed in pair order.  The count comes to the host: this
+    // is the one synchronisation of the call (its launch groups above never waited for the host).
+    int* list = need + npairs;
+    int* dcount = need + 2 * npairs;
+    k_flag_list<<<dim3(1), dim3(1024), 0, stream>>>(need, npairs, list, dcount);
+    PAL_HIP(hipGetLastError());
+    int count = 0;
+    PAL_HIP(hipMemcpyAsync(&count, dcount, sizeof count, hipMemcpyDeviceToHost, stream));
+    PAL_HIP(hipStreamSynchronize(stream));
+    if (count > 0) {
+      void *qp = nullptr, *tp = nullptr;
+      PAL_TRY(scratch(20, size_t((count + 1) / 2) * sizeof(int4), &qp));
+      PAL_TRY(scratch(21, size_t(count) * sizeof(pal_pair_record), &tp));
+      k_flag_quads<<<dim3(unsigned(((count + 1) / 2 + 255) / 256)), dim3(256), 0, stream>>>(quads, list, count, static_cast<int4*>(qp));
+      PAL_HIP(hipGetLastError());
+      const bool keep = fin_cols;
+      fin_cols = false;
+      const int rc = pair_correlations(pl, spectra, nspec, static_cast<const int4*>(qp), count, n2, prm, static_cast<pal_pair_record*>(tp), nullptr,
+                                       nullptr, nonzero);
+      fin_cols = keep;
+      PAL_TRY(rc);
+      k_flag_scatter<<<dim3(unsigned((count + 255) / 256)), dim3(256), 0, stream>>>(static_cast<const pal_pair_record*>(tp), list, count, table);
+      PAL_HIP(hipGetLastError());
     }
   }
   return PAL_OK;

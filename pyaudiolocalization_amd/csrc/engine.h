@@ -111,8 +111,8 @@ struct Engine {
   cd* stage_tw[16] = {};                        // stage-major twiddles per log2 N (<= 14: the big row tiles of pfa_big.h)
   cd* stage_twc[16] = {};                       // the same with a compact last stage (fft_core.h stage_twc_size)
   // growable device scratch
-  void* ws[16] = {};
-  size_t ws_bytes[16] = {};
+  void* ws[24] = {};              // (16..18: per-stream scratch of the finishing column pass, pfa_cols_fin.h; 19..21: its flagged pairs)
+  size_t ws_bytes[24] = {};
   // profiling
   bool profiling = false;
   int prof_every = 1;              // pair pipeline: events around every prof_every-th launch group only
@@ -170,12 +170,18 @@ struct Engine {
   int peaks_finish(PeakArgs& a, int rows, pal_pair_record* table, int32_t* ksel_multi, hipStream_t on);
   int pfa_rows(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, hipStream_t on);
   bool pfa_can_fuse(const Plan& pl) const;
+  bool pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const;   // pfa_cols_fin.h applies (one peak per row, N1 of 2..4 chunks)
+  int pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, const int* zero_rows,
+                         const pal_phat_params& prm, int n2, pal_pair_record* table, int* need, int slot, hipStream_t on);
   int pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, double* corr, size_t stride,
                            const int* zero_rows, const pal_phat_params& prm, int n2, pal_pair_record* table, int32_t* ksel_multi,
                            hipStream_t on);
   bool pfa_forward_applies(const Plan& pl, int len) const;
   int pfa_forward_spectra(Plan& pl, const double* frames, size_t frame_stride, int rows, int len, cd* spectra);
   bool pfa_forward = true;    // PAL_PFA_FWD=0: forward spectra on the four-step route even where the prime-factor cut applies
+  bool fin_cols = false;      // PAL_FIN=1: the column pass finishes the rows itself without storing them (pfa_cols_fin.h) instead of storing the
+                              // correlation rows for a finish launch (pfa_cols_stats.h).  Off by default: exact, 1.65 MB/pair of traffic instead of
+                              // 2.38, but its cross-block wait and serial finish cost more time than the stores they save
   bool fuse_peaks = true;     // PAL_FUSED=0: separate column pass + pivot / stream launches instead of the fused column pass +
                               // peak statistics (pfa_cols_stats.h) where that applies
 };

@@ -110,6 +110,11 @@ static int check_status(Engine* e) {
       fprintf(stderr, "[pal] %d row(s) needed the exact median (a threshold comparison inside the histogram interval)\n", exact);
       hipMemset(static_cast<int*>(e->ws[7]) + 3, 0, sizeof exact);
     }
+    int flagged = 0;
+    if (hipMemcpy(&flagged, static_cast<int*>(e->ws[7]) + 4, sizeof flagged, hipMemcpyDeviceToHost) == hipSuccess && flagged) {
+      fprintf(stderr, "[pal] %d row(s) of the finishing column pass went through the stored-row launches\n", flagged);
+      hipMemset(static_cast<int*>(e->ws[7]) + 4, 0, sizeof flagged);
+    }
   }
   int in = 0;                                // word 2: input problems found by device-side checks
   rc = e->check(hipMemcpy(&in, static_cast<int*>(e->ws[7]) + 2, sizeof in, hipMemcpyDeviceToHost), "status read");
@@ -122,6 +127,11 @@ static int check_status(Engine* e) {
   }
   if (st) {
     hipMemset(e->ws[7], 0, sizeof st);
+    if (st & 4) {
+      for (int k = 16; k < 19; ++k)                            // arrival counters of the finishing column pass start every launch at zero
+        if (e->ws[k]) hipMemset(e->ws[k], 0, e->ws_bytes[k] < 8192 ? e->ws_bytes[k] : 8192);
+      return e->fail(PAL_ERR_INTERNAL, "column pass: a workgroup gave up waiting for the other column blocks of its transform (the table of this call is not valid)");
+    }
     return e->fail(PAL_ERR_INTERNAL, "peak selection: suppression chain exceeded the on-chip memo/stack (rows fell back to argmax)");
   }
   return PAL_OK;
@@ -257,6 +267,8 @@ int pal_create(int device, pal_handle* out) {
   if (env) e->pfa_forward = atoi(env) != 0;
   env = getenv("PAL_FUSED");
   if (env) e->fuse_peaks = atoi(env) != 0;
+  env = getenv("PAL_FIN");
+  if (env) e->fin_cols = atoi(env) != 0;
   env = getenv("PAL_PFA_SUB");
   if (env) e->pfa_sub = atoi(env);
   env = getenv("PAL_MAX_PLANS");

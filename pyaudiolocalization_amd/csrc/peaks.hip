@@ -862,11 +862,10 @@ __global__ __launch_bounds__(kTS) void k_peak_stream(PeakArgs a) {
 
 // ------------------------------------------------------------------ 3. finish
 template <bool LOCAL>   // LOCAL: the segments are column blocks of the fused column pass (histogram windows, no pivots)
-__global__ __launch_bounds__(kT, 4) void k_peak_finish(PeakArgs a, pal_pair_record* table, int32_t* ksel_multi, int* status) {   // (4 waves per SIMD = two workgroups per CU: the launch is latency-bound)
+__device__ __forceinline__ void finish_row(const PeakArgs& a, pal_pair_record* table, int32_t* ksel_multi, int* status, const int row) {
   __shared__ Shared s;
   const int tid = threadIdx.x;
   const int S = a.splits;
-  const int row = blockIdx.x;
   const double* c = a.corr + size_t(row) * a.stride;
   const int n = a.n;
   const bool want_median = a.method == 0;
@@ -1232,6 +1231,11 @@ __global__ __launch_bounds__(kT, 4) void k_peak_finish(PeakArgs a, pal_pair_reco
       for (int k = 0; k < PAL_MAX_PEAKS; ++k) ksel_multi[size_t(row) * PAL_MAX_PEAKS + k] = k < count ? s.sel_pos[k] : -1;
     if (overflow) atomicOr(status, 1);
   }
+}
+
+template <bool LOCAL>
+__global__ __launch_bounds__(kT, 4) void k_peak_finish(PeakArgs a, pal_pair_record* table, int32_t* ksel_multi, int* status) {   // (4 waves per SIMD = two workgroups per CU: the launch is latency-bound)
+  finish_row<LOCAL>(a, table, ksel_multi, status, blockIdx.x);
 }
 
 }  // namespace

@@ -24,12 +24,16 @@
 // bluestein.hip PermSpectrumStorer): row N1-k1
 // is row k1 reversed and conjugated (Hermitian symmetry), so one workgroup serves both rows from the same
 // loads - tile 0 transforms x[k1, e], tile 1 the reversed row z[e] = x[N1-k1, -e], whose DFT is the reversed DFT.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "pfa_kernels.h"
 #include "pfa_rader.h"
 #include "pfa_cols_stats.h"
+#include "pfa_cols_fin.h"
 #include "pfa_forward.h"
 #include "pfa_big.h"
 
@@ -353,6 +357,132 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
     PAL_HIP(hipGetLastError());
   }
   return peaks_finish(a, rows, table, ksel_multi, on);
+}
+
+
+// ---- the column pass that finishes the rows itself (pfa_cols_fin.h): no correlation rows in HBM, no finish launch ----
+// One peak per row (main.py:204), the caller does not ask for `corr`, the column DFT has two to four chunks of output
+// indices (25 <= N1 <= 89) and rows of at least 128 columns.
+bool Engine::pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const {
+  const Pfa& f = pl.pfa;
+  return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.nch >= 2 && f.n2 >= 128;
+}
+
+int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, const int* zero_rows,
+                               const pal_phat_params& prm, int n2, pal_pair_record* table, int* need, int slot, hipStream_t on) {
+  const Pfa& f = pl.pfa;
+  const int nblk = (f.n2 + kColsOwn - 1) / kColsOwn;
+  const int n = pl.n;
+  PeakArgs a;
+  PAL_TRY(peaks_setup(nullptr, 0, rows, n, n2, prm, nblk, f.n2, on, a));
+  // per-stream scratch of the finishing pass: [counters 2 G | wsum | emax | parts | edge]
+  const int Gmax = pair_group(n);
+  const size_t off_wsum = (size_t(2 * Gmax) * sizeof(unsigned) + 127) & ~size_t(127);
+  const size_t off_emax = (off_wsum + size_t(2 * Gmax) * nblk * 2 * sizeof(double) + 127) & ~size_t(127);
+  const size_t off_parts = (off_emax + size_t(2 * Gmax) * nblk * 8 * sizeof(double) + 127) & ~size_t(127);
+  const size_t off_edge = (off_parts + size_t(2 * Gmax) * nblk * sizeof(FinPartial) + 127) & ~size_t(127);
+  const size_t total = off_edge + size_t(2 * Gmax) * 4 * f.n1 * sizeof(double);
+  void* sp = nullptr;
+  PAL_TRY(scratch(16 + slot, total, &sp));
+  char* base = static_cast<char*>(sp);
+  int* status = nullptr;
+  {
+    void* stp = nullptr;
+    PAL_TRY(scratch(7, 64, &stp));
+    status = static_cast<int*>(stp);
+  }
+  FinArgs fa;
+  fa.table = table;
+  fa.need = need;
+  fa.cnt = reinterpret_cast<unsigned*>(base);
+  fa.wsum = reinterpret_cast<double*>(base + off_wsum);
+  fa.emax = reinterpret_cast<double*>(base + off_emax);
+  fa.parts = reinterpret_cast<FinPartial*>(base + off_parts);
+  fa.edge = reinterpret_cast<double*>(base + off_edge);
+  fa.status = status;
+  // the lag window |m - (n2 - 1)| / fs <= max_expected_delay (utils.py:163) as sample indices, with the reference's arithmetic
+  fa.windowed = std::isnan(prm.max_expected_delay) ? 0 : 1;
+  fa.win_lo = 1;
+  fa.win_hi = n - 2;
+  if (fa.windowed) {
+    const double med = prm.max_expected_delay, fs = prm.fs;
+    long long k = -1;
+    if (med >= 0) {
+      const double est = med * fs;
+      k = est < double(n) ? (long long)est + 2 : (long long)n;
+      while (k >= 0 && !(std::fabs(double(k) / fs) <= med)) --k;
+    }
+    if (k < 0) { fa.win_lo = 1; fa.win_hi = 0; }
+    else {
+      const long long lo = (long long)(n2 - 1) - k, hi = (long long)(n2 - 1) + k;
+      fa.win_lo = int(lo < 1 ? 1 : lo);
+      fa.win_hi = int(hi > n - 2 ? n - 2 : hi);
+    }
+  }
+  fa.stamps = nullptr;
+  static const bool want_stamps = getenv("PAL_DEBUG_STAMPS") != nullptr;
+  const unsigned nwg = 8u * unsigned((G + 7) / 8) * unsigned(nblk);
+  if (want_stamps) {
+    void* st = nullptr;
+    PAL_TRY(scratch(13, size_t(nwg) * 8 * sizeof(unsigned long long), &st));
+    PAL_HIP(hipMemsetAsync(st, 0, size_t(nwg) * 8 * sizeof(unsigned long long), on));
+    fa.stamps = static_cast<unsigned long long*>(st);
+  }
+  PAL_TRY(pfa_rows(pl, permuted, quads, G, Y, on));
+  {
+    ProfScope ps(this, "k_pfa_cols_fin", on);
+    const dim3 grid(nwg);
+    const bool full = (f.n1 - 1) / 2 == f.nch * kPfaTC;
+    const bool adaptive = a.method > 0;
+    const int nw = f.nch == 2 ? 2 : 4;
+#define PAL_COLS_FIN(AD, FU, NW) k_pfa_cols_fin<kPfaTC, kPfaUnr, AD, FU, NW><<<grid, dim3(64 * NW), 0, on>>>(Y, f.n1, f.n2, G, f.nch, nblk, f.T, zero_rows, a, fa, rows)
+#define PAL_COLS_FIN_NW(AD, FU) do { if (nw == 2) PAL_COLS_FIN(AD, FU, 2); else PAL_COLS_FIN(AD, FU, 4); } while (0)
+    if (adaptive) { if (full) PAL_COLS_FIN_NW(true, true); else PAL_COLS_FIN_NW(true, false); }
+    else { if (full) PAL_COLS_FIN_NW(false, true); else PAL_COLS_FIN_NW(false, false); }
+#undef PAL_COLS_FIN_NW
+#undef PAL_COLS_FIN
+    PAL_HIP(hipGetLastError());
+  }
+  if (want_stamps) {                                           // diagnostics: phase times of this launch (synchronises)
+    std::vector<unsigned long long> hst(size_t(nwg) * 8);
+    PAL_HIP(hipStreamSynchronize(on));
+    PAL_HIP(hipMemcpy(hst.data(), fa.stamps, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const char* names[6] = {"accumulate", "pass A + windows", "pass B + publish", "wait for siblings", "window sums", "finish (last block)"};
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (unsigned b = 0; b < nwg; ++b)
+      if (hst[size_t(b) * 8]) { t0 = std::min(t0, hst[size_t(b) * 8]); for (int k = 0; k < 7; ++k) t1 = std::max(t1, hst[size_t(b) * 8 + k]); }
+    fprintf(stderr, "[pal] k_pfa_cols_fin: %u workgroups, first start to last stamp %.1f us\n", nwg, double(t1 - t0) / 100.0);
+    {
+      double life = 0;
+      std::vector<std::pair<unsigned long long, int>> ev;
+      for (unsigned b = 0; b < nwg; ++b) {
+        if (!hst[size_t(b) * 8]) continue;
+        unsigned long long e = 0;
+        for (int k = 0; k < 7; ++k) e = std::max(e, hst[size_t(b) * 8 + k]);
+        life += double(e - hst[size_t(b) * 8]) / 100.0;
+        ev.push_back({hst[size_t(b) * 8], 1});
+        ev.push_back({e, -1});
+      }
+      std::sort(ev.begin(), ev.end());
+      int cur = 0, peak = 0;
+      for (auto& x : ev) { cur += x.second; peak = std::max(peak, cur); }
+      fprintf(stderr, "[pal]   resident workgroups: average %.0f, peak %d; mean lifetime %.1f us\n", life / (double(t1 - t0) / 100.0), peak, life / nwg);
+      // when did the workgroups start (index order)?
+      for (unsigned b : {0u, 1u, 8u, 127u, 128u, 767u, 768u, 769u, 1535u, 1536u, 3071u, 3839u})
+        if (b < nwg) fprintf(stderr, "[pal]   workgroup %4u started at %7.1f us, ended at %7.1f\n", b, double(hst[size_t(b) * 8] - t0) / 100.0,
+                             double(std::max(hst[size_t(b) * 8 + 5], hst[size_t(b) * 8 + 6]) - t0) / 100.0);
+    }
+    std::vector<double> d;
+    for (int ph = 0; ph < 6; ++ph) {
+      d.clear();
+      for (unsigned b = 0; b < nwg; ++b)
+        if (hst[size_t(b) * 8 + ph] && hst[size_t(b) * 8 + ph + 1]) d.push_back(double(hst[size_t(b) * 8 + ph + 1] - hst[size_t(b) * 8 + ph]) / 100.0);
+      if (d.empty()) continue;
+      std::sort(d.begin(), d.end());
+      fprintf(stderr, "[pal]   %-20s n %5zu  median %7.2f us  p90 %7.2f us  max %7.2f us\n", names[ph], d.size(), d[d.size() / 2], d[d.size() * 9 / 10], d.back());
+    }
+  }
+  return PAL_OK;
 }
 
 }  // namespace pal

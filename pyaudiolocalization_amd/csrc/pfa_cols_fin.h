@@ -1,0 +1,718 @@
+// pfa_cols_fin.h - column pass of the prime-factor route that FINISHES the rows itself (gfx950, fp64): the correlation rows are
+// never written to HBM (`corr` leaves the chip only when the caller asks for it) and there is no finish launch.
+//
+// k_pfa_cols_stats (pfa_cols_stats.h) still stores the 0.7 MB per row because k_peak_finish reads a few thousand of them back:
+// the window around the maximum that compute_snr leaves out (utils.py:238-250), the grid's edge columns, and the
+// neighbourhoods of the candidates it resolves.  Here everything the selection of ONE peak per row (num_peaks = 1,
+// main.py:204) can need is taken from the samples while they are in the accumulators:
+//
+//   phase 1   as in k_pfa_cols_stats: histogram window of |x| around the block's median, maximum / first argmax, minimum,
+//             sums, highest strict peak, reported ties - plus, when the lag window max_expected_delay is set, the highest
+//             strict peak inside the window (it is kept by the distance rule unless a higher peak lies just outside the
+//             window, utils.py:152,163), and the four edge columns of the grid (their neighbours sit in another output
+//             index: tested by the finishing block).  A block whose samples at or above 0.8 x its maximum hold no strict
+//             peak tests ALL its samples again (registers, no memory), so every block reports its true best peak and
+//             nothing ever has to be rescanned.
+//   phase 2   the SNR window [argmax - w, argmax + w) needs the row's argmax, which only exists once all column blocks of
+//             the transform have seen their samples.  Every wavefront therefore publishes its maximum and the first index
+//             of it right behind pass A (one more look at its samples) and bumps the transform's counter; the blocks of one
+//             transform are adjacent in dispatch order (siblings are resident together), so by the time a block has done
+//             its histogram windows, pass B and the lag-window search, its siblings' maxima are there: one lane checks the
+//             counter (a bounded spin), then every wavefront sums ITS samples inside the window - still in registers.
+//   finish    the block that arrives last at the second counter merges the blocks' results of both rows: SNR, the
+//             threshold interval from the histogram windows, the fallback chain of utils.py:152-179 for one peak, and
+//             writes the 48-byte record.  A row whose selection needs what was not kept - a threshold comparison inside
+//             the median's interval, a tie that may outrank the best peak, a window peak closer than `distance` to the
+//             window's edge (a higher peak just outside could suppress it), a window that holds most of the row's
+//             energy - is flagged instead (need[pair] = 1): at the end of the call the engine runs the flagged pairs, in
+//             pair order, through the stored-row path (pfa_cols_stats.h + k_peak_finish) - exact for every input, and
+//             nothing extra is launched per group.
+//
+// Deadlock freedom of the wait: workgroups are dispatched in index order and the grid index interleaves the eight XCD
+// streams, so the siblings of a block lie within 8 x blocks-per-transform consecutive indices; a waiting block's
+// siblings are resident or next in line, and blocks that do not wait finish on their own.  The spin is bounded anyway
+// (status bit 4 -> PAL_ERR_INTERNAL) so that a violated assumption cannot hang the device.
+#pragma once
+#include <climits>
+
+#include "pfa_cols_stats.h"
+#include "reduce.h"
+
+namespace pal {
+
+struct FinPartial {               // what one column block hands to the finishing block, per row (whole 8-byte words)
+  double vmin, hb, plat;          // minimum; highest strict peak (mb = -1: none); highest sample with an equal neighbour (-inf: none)
+  double s1, s2, a1;              // sum x, sum x^2, sum |x|
+  double hw, platw;               // lag window: highest strict peak inside it (mw = -1: none), highest tie inside it
+  int mb, mw;
+};
+static_assert(sizeof(FinPartial) == 72, "nine words");
+
+struct FinArgs {
+  pal_pair_record* table;         // [rows] records of this launch group
+  int* need;                      // [rows] of this launch group inside the call-wide flag array: 1 = the pair goes through the stored-row path
+  unsigned* cnt;                  // [2 G] arrivals of the wavefronts' maxima / of the blocks' window sums (zero between launches)
+  double* edge;                   // [rows][4][N1] columns 0, 1, N2 - 2, N2 - 1 of the grid
+  double* wsum;                   // [rows][S][2] window sums of the blocks
+  double* emax;                   // [rows][S][4][2] every wavefront's (maximum, first index of it as a double), published behind pass A
+  FinPartial* parts;              // [rows][S]
+  int* status;                    // engine status words (bit 2 of word 0: a wait timed out; word 4: flagged rows)
+  int win_lo, win_hi;             // lag window as sample indices, |m - (n2 - 1)| / fs <= max_expected_delay (win_lo > win_hi: empty)
+  int windowed;
+  unsigned long long* stamps;     // diagnostics (PAL_DEBUG_STAMPS=1): [workgroup][8] 100 MHz clock reads of lane 0 per phase
+};
+
+struct FinWave {                  // one wavefront's share of the finishing block's merge
+  double vmax, hb, hw, plat, platw, nvmin, s1, s2, a1, w1, w2;
+  int imax, mb, mw, pad;
+};
+
+struct FinShared {                // finishing block's scratch, laid over the histograms of phase 1
+  unsigned hwin[2 * kWin];
+  int swin0[144];
+  FinWave wave[4];
+};
+static_assert(sizeof(FinShared) <= 2 * (kLogBins + 1) * sizeof(unsigned), "the finish scratch aliases the histograms");
+
+// What the column blocks of a transform hand to each other travels in device-scope relaxed atomic stores and loads (sc1:
+// through the caches to the coherence point) - no release / acquire fences, which on this part write back and invalidate the
+// whole L2 (buffer_wbl2 / buffer_inv: eight of them per workgroup made this kernel five times slower than its arithmetic).
+// Order: a wavefront waits for its own stores (s_waitcnt vmcnt(0)) before it - or, behind a workgroup barrier, lane 0 - bumps
+// the counter; a reader sees the counter, passes a barrier, and only then issues its loads.
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<long long*>(p), __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T> __device__ __forceinline__ void st_words(T* dst, const T& v) {           // a struct of whole 8-byte words
+  static_assert(sizeof(T) % 8 == 0, "whole words");
+  const long long* src = reinterpret_cast<const long long*>(&v);
+  long long* d = reinterpret_cast<long long*>(dst);
+#pragma unroll
+  for (int k = 0; k < int(sizeof(T) / 8); ++k) __hip_atomic_store(d + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T> __device__ __forceinline__ T ld_words(const T* src) {
+  T v;
+  long long* d = reinterpret_cast<long long*>(&v);
+  const long long* s = reinterpret_cast<const long long*>(src);
+#pragma unroll
+  for (int k = 0; k < int(sizeof(T) / 8); ++k) d[k] = __hip_atomic_load(s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// one lane waits until *p >= want (the others sit at the barrier behind it); false: gave up
+__device__ __forceinline__ bool spin_until(const unsigned* p, unsigned want, const int* status) {
+  for (int spins = 0; spins < (1 << 17); ++spins) {            // (a fraction of a second; siblings arrive within microseconds)
+    if (ld_agent(p) >= want) return true;
+    if ((spins & 255) == 255 && (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) return false;   // another block gave up: the call has failed
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return false;
+}
+
+// ---- the finishing block: one row from the blocks' published results (all LANES lanes, uniform control flow) ----
+template <int LANES>
+__device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, int row, int N1, int N2, int nch, FinShared& fs, int tid) {
+  constexpr int NW = LANES / 64;
+  const int S = pa.splits, n = pa.n;
+  const bool windowed = fa.windowed != 0;
+  const bool want_median = pa.method == 0;
+  // ---- every lane: some wavefronts' maxima, at most a few blocks' results and edge samples; merged locally, then across the workgroup
+  double vmax = 0, vmin = INFINITY, hb = 0, plat = -INFINITY, s1 = 0, s2 = 0, a1 = 0, w1 = 0, w2 = 0;
+  int imax = -1, mb = -1;
+  double hw = 0, platw = -INFINITY;
+  int mw = -1;
+  {
+    const double* em = fa.emax + size_t(row) * S * 8;
+    for (int q = tid; q < S * 4; q += LANES) {
+      if ((q & 3) >= nch) continue;
+      const double v = ld_agent(em + 2 * q);
+      const int i = int(ld_agent(em + 2 * q + 1));
+      if (i >= 0 && i < n && (imax < 0 || arg_better<0>(v, i, vmax, imax))) { vmax = v; imax = i; }
+    }
+  }
+  for (int q = tid; q < S; q += LANES) {
+    const FinPartial pt = ld_words(fa.parts + size_t(row) * S + q);
+    vmin = fmin(vmin, pt.vmin);
+    if (pt.mb >= 0 && (mb < 0 || higher(pt.hb, pt.mb, hb, mb))) { hb = pt.hb; mb = pt.mb; }
+    plat = fmax(plat, pt.plat);
+    s1 += pt.s1; s2 += pt.s2; a1 += pt.a1;
+    w1 += ld_agent(fa.wsum + (size_t(row) * S + q) * 2);
+    w2 += ld_agent(fa.wsum + (size_t(row) * S + q) * 2 + 1);
+    if (windowed) {
+      if (pt.mw >= 0 && (mw < 0 || higher(pt.hw, pt.mw, hw, mw))) { hw = pt.hw; mw = pt.mw; }
+      platw = fmax(platw, pt.platw);
+    }
+  }
+  // the grid's first and last column: neighbours in another output index (m - 1 = (N2 - 1, t - 1), m + 1 = (0, t + 1))
+  const double* E = fa.edge + size_t(row) * 4 * N1;
+  for (int k = tid; k < 2 * N1; k += LANES) {
+    const bool first = k < N1;
+    const int t = first ? k : k - N1;
+    const int m = first ? N2 * t : N2 * t + N2 - 1;
+    if (m < 1 || m > n - 2) continue;                          // the row's end points are never peaks
+    const double x = ld_agent(first ? E + t : E + 3 * N1 + t);
+    const double xl = ld_agent(first ? E + 3 * N1 + t - 1 : E + 2 * N1 + t);
+    const double xr = ld_agent(first ? E + N1 + t : E + t + 1);
+    const bool tie = xl == x || xr == x;
+    const bool pk = xl < x && xr < x;
+    const bool inw = windowed && m >= fa.win_lo && m <= fa.win_hi;
+    if (tie) plat = fmax(plat, x);
+    if (tie && inw) platw = fmax(platw, x);
+    if (pk && (mb < 0 || higher(x, m, hb, mb))) { hb = x; mb = m; }
+    if (pk && inw && (mw < 0 || higher(x, m, hw, mw))) { hw = x; mw = m; }
+  }
+  {
+    double nvmin = -vmin;
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = shfl_down_d(vmax, o);
+      const int oi = __shfl_down(imax, o, 64);
+      if (oi >= 0 && (imax < 0 || arg_better<0>(ov, oi, vmax, imax))) { vmax = ov; imax = oi; }
+      const double hv = shfl_down_d(hb, o);
+      const int hi_ = __shfl_down(mb, o, 64);
+      if (hi_ >= 0 && (mb < 0 || higher(hv, hi_, hb, mb))) { hb = hv; mb = hi_; }
+      const double wv = shfl_down_d(hw, o);
+      const int wi = __shfl_down(mw, o, 64);
+      if (wi >= 0 && (mw < 0 || higher(wv, wi, hw, mw))) { hw = wv; mw = wi; }
+      plat = fmax(plat, shfl_down_d(plat, o));
+      platw = fmax(platw, shfl_down_d(platw, o));
+      nvmin = fmax(nvmin, shfl_down_d(nvmin, o));
+      s1 += shfl_down_d(s1, o); s2 += shfl_down_d(s2, o); a1 += shfl_down_d(a1, o);
+      w1 += shfl_down_d(w1, o); w2 += shfl_down_d(w2, o);
+    }
+    __syncthreads();                                           // (the previous row's readers are done with the scratch)
+    if ((tid & 63) == 0) {
+      FinWave& w = fs.wave[tid >> 6];
+      w.vmax = vmax; w.imax = imax; w.hb = hb; w.mb = mb; w.hw = hw; w.mw = mw; w.plat = plat; w.platw = platw; w.nvmin = nvmin;
+      w.s1 = s1; w.s2 = s2; w.a1 = a1; w.w1 = w1; w.w2 = w2;
+    }
+    __syncthreads();
+    const FinWave w0 = fs.wave[0];
+    vmax = w0.vmax; imax = w0.imax; hb = w0.hb; mb = w0.mb; hw = w0.hw; mw = w0.mw; plat = w0.plat; platw = w0.platw; nvmin = w0.nvmin;
+    s1 = w0.s1; s2 = w0.s2; a1 = w0.a1; w1 = w0.w1; w2 = w0.w2;
+    for (int k = 1; k < NW; ++k) {
+      const FinWave w = fs.wave[k];
+      if (w.imax >= 0 && (imax < 0 || arg_better<0>(w.vmax, w.imax, vmax, imax))) { vmax = w.vmax; imax = w.imax; }
+      if (w.mb >= 0 && (mb < 0 || higher(w.hb, w.mb, hb, mb))) { hb = w.hb; mb = w.mb; }
+      if (w.mw >= 0 && (mw < 0 || higher(w.hw, w.mw, hw, mw))) { hw = w.hw; mw = w.mw; }
+      plat = fmax(plat, w.plat); platw = fmax(platw, w.platw); nvmin = fmax(nvmin, w.nvmin);
+      s1 += w.s1; s2 += w.s2; a1 += w.a1; w1 += w.w1; w2 += w.w2;
+    }
+    vmin = -nvmin;
+  }
+  bool flag = false;                                           // the row needs its samples: stored-row path at the end of the call
+  if (imax < 0 || imax >= n) { imax = 0; flag = true; }
+  // a tie that may outrank the best strict peak (plateaus are resolved from the stored row)
+  if (plat > -INFINITY && (mb < 0 || plat >= hb)) flag = true;
+  if (windowed && platw > -INFINITY && (mw < 0 || platw >= hw)) flag = true;
+
+  // ---- SNR (utils.py:238-250): totals minus the window around the maximum
+  const int wlo_s = imax - pa.snr_w > 0 ? imax - pa.snr_w : 0;
+  const int whi_s = imax + pa.snr_w < n ? imax + pa.snr_w : n;
+  const double nn = double(n - (whi_s - wlo_s));
+  const double o1 = s1 - w1, o2 = s2 - w2;
+  if (!(o2 >= 0.25 * s2)) flag = true;                         // the window holds most of the energy: two-pass sum of the noise region
+  double var = (o2 - o1 * o1 / nn) / nn;
+  if (var < 0) var = 0;
+  const double noise = sqrt(var);
+  const double snr = noise == 0.0 ? INFINITY : vmax / noise;
+
+  // ---- primary threshold (utils.py:144-149): exact ('adaptive'), or an interval from the blocks' histogram windows
+  double tlo = 0, thi = 0;
+  if (!want_median) {
+    double va = (s2 - a1 * a1 / double(n)) / double(n);
+    if (va < 0) va = 0;
+    tlo = thi = pa.mult * (a1 / double(n) + sqrt(va));         // utils.py:147
+  } else {
+    const unsigned r1 = unsigned((n - 1) / 2), r2 = unsigned(n / 2);
+    const BlockHist* bh = pa.bh + size_t(row) * S;
+    bool have = S <= 144;
+    if (tid < 2 * kWin) fs.hwin[tid] = 0;
+    if (tid < S && tid < 144) fs.swin0[tid] = ld_agent(&bh[tid].win0);
+    __syncthreads();
+    int w0 = 0, wend = kLogBins;
+    for (int q = 0; q < S && q < 144; ++q) {
+      const int v = fs.swin0[q];
+      w0 = v > w0 ? v : w0;
+      wend = v + kWin < wend ? v + kWin : wend;
+    }
+    for (int q = tid; q < S && have; q += LANES) {
+      atomicAdd(&fs.hwin[kWin], ld_agent(&bh[q].below));
+      atomicAdd(&fs.hwin[kWin + 1], ld_agent(&bh[q].total));
+    }
+    for (int e = tid; e < S * kWin && have; e += LANES) {
+      const int q = e / kWin, k = e - q * kWin;
+      const int b = fs.swin0[q] + k;
+      const unsigned v = ld_agent(&bh[q].h[k]);
+      if (b < w0) atomicAdd(&fs.hwin[kWin], v);
+      else if (b < wend) atomicAdd(&fs.hwin[b - w0], v);
+    }
+    __syncthreads();
+    const unsigned total = fs.hwin[kWin + 1], base = fs.hwin[kWin];
+    have = have && w0 < wend && total == unsigned(n) && r1 >= base;
+    double b1lo = 0, b1hi = 0, b2lo = 0, b2hi = 0;
+    if (have) {
+      unsigned e = base;
+      int f1 = -1, f2 = -1;
+      for (int k = 0; k < wend - w0; ++k) {
+        const unsigned v = fs.hwin[k];
+        if (f1 < 0 && r1 < e + v) f1 = k;
+        if (f2 < 0 && r2 < e + v) f2 = k;
+        e += v;
+      }
+      have = f1 >= 0 && f2 >= 0;
+      if (have) {
+        b1lo = log_bin_floor(w0 + f1); b1hi = log_bin_floor(w0 + f1 + 1);
+        b2lo = log_bin_floor(w0 + f2); b2hi = log_bin_floor(w0 + f2 + 1);
+      }
+    }
+    __syncthreads();
+    if (have) {                                                // np.median = the middle value, or the mean of the two middle ones
+      const double ml_ = r2 != r1 ? (b1lo + b2lo) * 0.5 : b1lo, mh_ = r2 != r1 ? (b1hi + b2hi) * 0.5 : b1hi;
+      tlo = pa.mult >= 0 ? pa.mult * ml_ : pa.mult * mh_;
+      thi = pa.mult >= 0 ? pa.mult * mh_ : pa.mult * ml_;
+    } else {
+      flag = true;                                             // the windows missed the row's median: exact select over the stored row
+    }
+  }
+
+  // ---- the fallback chain of utils.py:152-179 for ONE peak
+  const double mean_abs = a1 / double(n);
+  int branch = 0, sel = imax;
+  double sel_h = vmax;
+  bool argmax_fallback = false;
+  if (!flag) {
+    bool alt = false;
+    if (mb >= 0 && hb >= thi) {
+    } else if (mb >= 0 && hb >= tlo) {
+      flag = true;                                             // inside the median's interval
+    } else {
+      branch |= PAL_BR_ALT_THRESHOLD;
+      alt = true;
+      if (!(mb >= 0 && hb >= mean_abs)) { branch |= PAL_BR_ARGMAX_NO_PEAKS; argmax_fallback = true; }
+    }
+    if (!flag && !argmax_fallback) {
+      if (!windowed) {
+        sel = mb; sel_h = hb;                                  // the highest peak of the row is kept by the distance rule
+      } else {
+        const double t_lo = alt ? mean_abs : tlo, t_hi = alt ? mean_abs : thi;
+        bool found = false;
+        if (mw >= 0 && hw >= t_hi) found = true;
+        else if (mw >= 0 && hw >= t_lo) flag = true;
+        if (!flag && !found) {                                 // no peak of the first search inside the window: mean(|corr|), then argmax
+          branch |= PAL_BR_WINDOW_RETRY;
+          if (mw >= 0 && hw >= mean_abs) found = true;
+          else { branch |= PAL_BR_ARGMAX_WINDOW; argmax_fallback = true; }
+        }
+        if (found) {
+          // the window's best peak is kept unless a HIGHER peak lies closer than `distance`; inside the window there is none,
+          // and a sample outside it is that close only to peaks within distance - 2 of the window's edge
+          if (mw - fa.win_lo < pa.dist - 1 || fa.win_hi - mw < pa.dist - 1) flag = true;
+          else { sel = mw; sel_h = hw; }
+        }
+      }
+    }
+    if (argmax_fallback) { sel = imax; sel_h = vmax; }
+  }
+  if (tid == 0) {
+    fa.need[row] = flag ? 1 : 0;
+    if (flag) atomicAdd(fa.status + 4, 1);
+    else {
+      pal_pair_record r;
+      r.k_sel = sel; r.branch = branch; r.k_argmax = imax; r.n_sel = 1;
+      r.cmax = vmax; r.cmin = vmin; r.snr = snr; r.sel_height = sel_h;
+      fa.table[row] = r;
+    }
+  }
+}
+
+// grid: 8 * ceil(G / 8) * nblk workgroups; index b -> XCD stream b & 7, slot b >> 3; the transforms g = x, x + 8, ... of stream x
+// take nblk consecutive slots each (siblings adjacent, one XCD's L2 behind them when G is a multiple of 8)
+template <int TC, int UNR, bool ADAPTIVE, bool FULL, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) void k_pfa_cols_fin(const cd* __restrict__ Y, int N1, int N2, int G, int nch, int nblk,
+                                                      const double* __restrict__ T, const int* __restrict__ zero_rows, PeakArgs pa,
+                                                      FinArgs fa, int rows) {
+  __shared__ unsigned hist[2][kLogBins + 1];
+  __shared__ FinPartial res[4][2];
+  __shared__ double wmax[4][2];
+  __shared__ unsigned wtot[4][2];
+  __shared__ int medbin[2];
+  __shared__ int s_imax[2];
+  __shared__ double wred[4][2][2];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = wave;
+  const int xs = int(blockIdx.x & 7u), slot = int(blockIdx.x >> 3);
+  const int cb = slot % nblk, g = xs + 8 * (slot / nblk);
+  if (g >= G) return;                                          // (uniform: the grid is padded to whole XCD rounds)
+  int stamp_at = 0;
+  auto stamp = [&]() {
+    if (fa.stamps && tid == 0) fa.stamps[size_t(blockIdx.x) * 8 + stamp_at] = __builtin_amdgcn_s_memrealtime();
+    ++stamp_at;
+  };
+  stamp();
+  const int c_lo = int((long long)cb * N2 / nblk), c_hi = int((long long)(cb + 1) * N2 / nblk);   // owned columns [c_lo, c_hi)
+  const bool active = ch < nch;
+  const int m2 = c_lo - 1 + lane;
+  const bool live = m2 >= 0 && m2 < N2 && lane <= c_hi - c_lo + 1;
+  const bool own = live && lane >= 1 && lane <= c_hi - c_lo;
+  const bool inner = own && m2 >= 1 && m2 <= N2 - 2;
+  const int m2c = m2 < 0 ? 0 : (m2 < N2 ? m2 : N2 - 1);
+  const cd* Yg = Y + size_t(g) * N1 * N2 + m2c;
+  const int h = (N1 - 1) / 2;
+  const int n = pa.n;
+  constexpr bool want_median = !ADAPTIVE;
+  constexpr int LANES = 64 * NW;
+  if (want_median) {
+    unsigned* hz = &hist[0][0];
+    for (int q = tid; q < 2 * (kLogBins + 1); q += LANES) hz[q] = 0;
+  }
+  double cx[TC], sy[TC], cy[TC], sx[TC];
+  double sumx = 0, sumy = 0;
+  cd y0 = mk(0, 0);
+  if (active) pfa_cols_accumulate<TC, UNR>(Yg, N1, N2, nch, ch, T, y0, cx, sy, cy, sx, sumx, sumy);
+  {
+    const double kp = zero_rows && zero_rows[2 * g] ? 0.0 : 1.0, kq = zero_rows && 2 * g + 1 < rows && zero_rows[2 * g + 1] ? 0.0 : 1.0;
+    if (kp == 0.0) { y0.x = sumx = 0.0; }
+    if (kq == 0.0) { y0.y = sumy = 0.0; }
+#pragma unroll
+    for (int tt = 0; tt < TC; ++tt) {
+      cx[tt] *= kp; sy[tt] *= kp; cy[tt] *= kq; sx[tt] *= kq;
+    }
+  }
+  stamp();                                                     // 1: accumulated
+  // the samples of this lane in lag order: t = 0 (chunk 0 only), the chunk ascending, the mirrors descending.
+  // fn(value, t, exists): `value()` forms the sample (two additions) only where it is wanted; t and `exists` are wave-uniform
+  auto each_sample = [&](int r, auto&& fn) {
+    const double base = r ? y0.y : y0.x;
+    fn([&]() { return base + (r ? sumy : sumx); }, 0, ch == 0);
+#pragma unroll
+    for (int tt = 0; tt < TC; ++tt) {
+      const int t = ch * TC + tt + 1;
+      fn([&]() { return r ? base + cy[tt] + sx[tt] : base + cx[tt] - sy[tt]; }, t, FULL || t <= h);
+    }
+#pragma unroll
+    for (int tt = TC - 1; tt >= 0; --tt) {
+      const int t = ch * TC + tt + 1;
+      fn([&]() { return r ? base + cy[tt] - sx[tt] : base + cx[tt] + sy[tt]; }, N1 - t, FULL || t <= h);
+    }
+  };
+  __syncthreads();
+
+  // ---- pass A: histogram of |x| (exact counts), maximum with its first index, minimum, sums
+  const int nrow = 2 * g + 1 < rows ? 2 : 1;
+  constexpr unsigned kBase4 = unsigned(1023 * 128 - kLogBins) * 4u, kTop4 = kBase4 + unsigned(kLogBins - 1) * 4u;
+  const unsigned lift = own ? 0u : unsigned(kLogBins) * 4u;
+  const unsigned one = 1u;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    double vm = -INFINITY, vn = INFINITY, s1 = 0, s2 = 0, a1 = 0;
+    int tm = 0;                                                // output index of the lane's maximum (samples come in lag order: the first one stays)
+    if (active && r < nrow) {
+      char* const hrow = reinterpret_cast<char*>(&hist[r][0]);
+      each_sample(r, [&](auto&& value, int t, bool exists) {
+        if (!exists) return;
+        const double x = value();
+        const bool up = x > vm;
+        vm = up ? x : vm;
+        tm = up ? t : tm;
+        vn = min_raw(vn, x);
+        s1 += x;
+        s2 = __builtin_fma(x, x, s2);
+        a1 += fabs(x);
+        if (want_median) {
+          const unsigned key4 = (unsigned(__double2hiint(x)) & 0x7fffe000u) >> 11;
+          const unsigned off = max(min(max(key4, kBase4), kTop4) - kBase4, lift);
+          atomicAdd(reinterpret_cast<unsigned*>(hrow + off), one);
+        }
+      });
+    }
+    int im = own && vm > -INFINITY ? m2 + N2 * tm : -1;
+    if (!own) { vm = -INFINITY; vn = INFINITY; s1 = s2 = a1 = 0; }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = shfl_down_d(vm, o);
+      const int oi = __shfl_down(im, o, 64);
+      if (oi >= 0 && (im < 0 || arg_better<0>(ov, oi, vm, im))) { vm = ov; im = oi; }
+      vn = fmin(vn, shfl_down_d(vn, o));
+      s1 += shfl_down_d(s1, o);
+      s2 += shfl_down_d(s2, o);
+      a1 += shfl_down_d(a1, o);
+    }
+    if (lane == 0) {
+      wmax[wave][r] = vm;
+      FinPartial& w = res[wave][r];
+      w.vmin = vn; w.s1 = s1; w.s2 = s2; w.a1 = a1;
+      // the wavefront's maximum and the first index of it go out NOW: the siblings need the row's argmax for their SNR window
+      // sums, and published here it has arrived by the time they are through their own pass B
+      if (active && r < nrow) {
+        double* dst = fa.emax + ((size_t(2 * g + r) * pa.splits + cb) * 4 + wave) * 2;
+        st_agent(dst, vm); st_agent(dst + 1, double(im));
+      }
+    }
+  }
+  if (active) {                                                // (uniform) one arrival per active wavefront
+    stores_done();
+    if (lane == 0) atomicAdd(&fa.cnt[g], 1u);
+  }
+  __syncthreads();
+  // ---- the block's median bin per row, then the window around it is published
+  if (want_median) {
+    constexpr int PER = kLogBins / LANES;
+    unsigned hv[2][PER], sum[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < PER; ++q) { hv[r][q] = hist[r][PER * tid + q]; sum[r] += hv[r][q]; }
+    unsigned inc[2] = {sum[0], sum[1]};
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t0 = __shfl_up(inc[0], o, 64), t1 = __shfl_up(inc[1], o, 64);
+      if (lane >= o) { inc[0] += t0; inc[1] += t1; }
+    }
+    if (lane == 63) { wtot[wave][0] = inc[0]; wtot[wave][1] = inc[1]; }
+    if (tid < 2) medbin[tid] = 0;
+    __syncthreads();
+    unsigned ex[2], cnt[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned before = 0;
+      cnt[r] = 0;
+      for (int w = 0; w < NW; ++w) { before += w < wave ? wtot[w][r] : 0; cnt[r] += wtot[w][r]; }
+      ex[r] = before + inc[r] - sum[r];
+      const unsigned mid = cnt[r] >> 1;
+      unsigned e = ex[r];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        if (hv[r][q] && mid >= e && mid < e + hv[r][q]) medbin[r] = PER * tid + q;
+        e += hv[r][q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (2 * g + r >= rows) continue;
+      int w0 = medbin[r] - kWin / 2;
+      w0 = w0 < 0 ? 0 : (w0 > kLogBins - kWin ? kLogBins - kWin : w0);
+      BlockHist* bh = pa.bh + size_t(2 * g + r) * pa.splits + cb;
+      if (w0 >= PER * tid && w0 < PER * tid + PER) {
+        unsigned below = ex[r];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) below += PER * tid + q < w0 ? hv[r][q] : 0u;
+        st_agent(reinterpret_cast<unsigned*>(&bh->win0), unsigned(w0)); st_agent(&bh->below, below); st_agent(&bh->total, cnt[r]);
+      }
+      if (tid < kWin) st_agent(&bh->h[tid], hist[r][w0 + tid]);
+    }
+  }
+
+  // ---- the grid's edge columns go to the finishing block as they are (blocks 0 and nblk - 1 only)
+  if ((c_lo == 0 || c_hi == N2) && active) {                   // (uniform)
+    const bool mine = own && (m2 <= 1 || m2 >= N2 - 2);
+    const int e = m2 <= 1 ? m2 : 3 - (N2 - 1 - m2);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (2 * g + r >= rows) continue;
+      double* dst = fa.edge + (size_t(2 * g + r) * 4 + (mine ? e : 0)) * N1;
+      each_sample(r, [&](auto&& value, int t, bool exists) {
+        if (!exists) return;
+        const double x = value();
+        if (mine) st_agent(dst + t, x);
+      });
+    }
+  }
+  stamp();                                                     // 2: pass A, histogram windows, edge columns
+
+  // ---- pass B: the highest strict peak behind the block's exact bound; a block whose bounded search found no peak
+  //      searches all its samples (second round), so its result is exact
+  const bool windowed = fa.windowed != 0;
+  double pfl[2];
+  bool redo[2] = {false, false};
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    double vfloor = wmax[0][r];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) vfloor = fmax(vfloor, wmax[w][r]);
+    pfl[r] = vfloor > 0 ? 0.8 * vfloor : -INFINITY;
+  }
+#pragma nounroll
+  for (int round = 0; round < 2; ++round) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = 2 * g + r;
+      if (row >= rows || (round == 1 && !redo[r])) continue;   // (uniform)
+      const double pfloor = round == 0 ? pfl[r] : -INFINITY;
+      const double myfloor = inner ? pfloor : INFINITY;        // (the grid's edge columns are the finishing block's)
+      double hb = -INFINITY, plat = -INFINITY;
+      int mb = -1;
+      if (active) {
+        each_sample(r, [&](auto&& value, int t, bool exists) {
+          if (!exists) return;
+          const double x = value();
+          if (__ballot(x >= myfloor)) {
+            const int m = m2 + N2 * t;
+            const double left = from_lower_lane(x), right = from_upper_lane(x);
+            const bool cand = inner && x >= pfloor && x >= hb;
+            const bool pk = cand && left < x && right < x;
+            hb = pk ? x : hb;
+            mb = pk ? m : mb;
+            plat = inner && x >= pfloor && left == x ? fmax(plat, x) : plat;
+          }
+        });
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double hv = shfl_down_d(hb, o);
+        const int hi_ = __shfl_down(mb, o, 64);
+        if (hi_ >= 0 && (mb < 0 || higher(hv, hi_, hb, mb))) { hb = hv; mb = hi_; }
+        plat = fmax(plat, shfl_down_d(plat, o));
+      }
+      if (lane == 0) {
+        FinPartial& w = res[wave][r];
+        w.hb = hb; w.plat = plat; w.mb = mb;
+      }
+      // the lag window: its highest strict peak, whatever its height (a handful of output indices meet the window)
+      if (windowed && round == 0) {
+        const int lo1 = fa.win_lo > 1 ? fa.win_lo : 1, hi1 = fa.win_hi < n - 2 ? fa.win_hi : n - 2;   // (the row's end points are never peaks)
+        const int t_lo = lo1 / N2, t_hi = hi1 / N2;
+        double hq = -INFINITY, platw = -INFINITY;
+        int mq = -1;
+        if (active && lo1 <= hi1) {
+          each_sample(r, [&](auto&& value, int t, bool exists) {
+            if (!exists || t < t_lo || t > t_hi) return;       // (uniform)
+            const double x = value();
+            const int m = m2 + N2 * t;
+            const double left = from_lower_lane(x), right = from_upper_lane(x);
+            const bool in = inner && m >= lo1 && m <= hi1;
+            platw = in && (left == x || right == x) ? fmax(platw, x) : platw;
+            if (in && left < x && right < x && x >= hq) { hq = x; mq = m; }
+          });
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+          const double v = shfl_down_d(hq, o);
+          const int i = __shfl_down(mq, o, 64);
+          if (i >= 0 && (mq < 0 || higher(v, i, hq, mq))) { hq = v; mq = i; }
+          platw = fmax(platw, shfl_down_d(platw, o));
+        }
+        if (lane == 0) {
+          FinPartial& w = res[wave][r];
+          w.hw = hq; w.mw = mq; w.platw = platw;
+        }
+      }
+    }
+    __syncthreads();
+    if (round == 1) break;
+    bool again = false;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      bool any = false;
+      for (int w = 0; w < NW; ++w) any = any || res[w][r].mb >= 0;
+      redo[r] = 2 * g + r < rows && !any && pfl[r] > -INFINITY;
+      again = again || redo[r];
+    }
+    if (!again) break;                                         // (uniform: every lane read the same LDS words)
+    __syncthreads();
+  }
+  // ---- publish: lanes 0 / 1 merge the wavefronts of row p / q
+  if (tid < 2 && 2 * g + tid < rows) {
+    const int r = tid, row = 2 * g + r;
+    FinPartial pt;
+    pt.hb = pt.plat = pt.platw = -INFINITY;
+    pt.vmin = INFINITY;
+    pt.mb = pt.mw = -1;
+    pt.s1 = pt.s2 = pt.a1 = pt.hw = 0;
+    for (int w = 0; w < NW; ++w) {
+      const FinPartial x = res[w][r];
+      pt.vmin = fmin(pt.vmin, x.vmin);
+      if (x.mb >= 0 && (pt.mb < 0 || higher(x.hb, x.mb, pt.hb, pt.mb))) { pt.hb = x.hb; pt.mb = x.mb; }
+      pt.s1 += x.s1; pt.s2 += x.s2; pt.a1 += x.a1;
+      pt.plat = fmax(pt.plat, x.plat);
+      if (windowed) {
+        if (x.mw >= 0 && (pt.mw < 0 || higher(x.hw, x.mw, pt.hw, pt.mw))) { pt.hw = x.hw; pt.mw = x.mw; }
+        pt.platw = fmax(pt.platw, x.platw);
+      }
+    }
+    st_words(fa.parts + size_t(row) * pa.splits + cb, pt);
+  }
+
+  // ---- phase 2: the siblings' maxima (published long ago), then the SNR window sums of this block's samples
+  stamp();                                                     // 3: pass B, published
+  if (tid == 0) {
+    s_flag = spin_until(&fa.cnt[g], unsigned(nblk * nch), fa.status) ? 0 : 1;
+    if (s_flag) atomicOr(fa.status, 4);
+  }
+  __syncthreads();
+  stamp();                                                     // 4: the siblings' maxima have arrived
+  if (wave < 2 && 2 * g + wave < rows) {
+    const int row = 2 * g + wave;
+    double bv = 0;
+    int bi = -1;
+    const double* em = fa.emax + size_t(row) * pa.splits * 8;
+    for (int q = lane; q < pa.splits * 4; q += 64) {           // (entry = block * 4 + wavefront; idle wavefronts never wrote theirs)
+      if ((q & 3) >= nch) continue;
+      const double v = ld_agent(em + 2 * q);
+      const int i = int(ld_agent(em + 2 * q + 1));
+      if (i >= 0 && i < n && (bi < 0 || arg_better<0>(v, i, bv, bi))) { bv = v; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = shfl_down_d(bv, o);
+      const int oi = __shfl_down(bi, o, 64);
+      if (oi >= 0 && (bi < 0 || arg_better<0>(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) s_imax[wave] = bi;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (2 * g + r >= rows) continue;
+    int imax = s_imax[r];
+    if (imax < 0 || imax >= n) imax = 0;
+    const int A = imax - pa.snr_w > 0 ? imax - pa.snr_w : 0, B = imax + pa.snr_w < n ? imax + pa.snr_w : n;   // [A, B)
+    const int tA = A / N2, tB = (B - 1) / N2;
+    const bool inA = m2 >= A - tA * N2, inB = m2 < B - tB * N2;
+    double w1 = 0, w2 = 0;
+    if (active) {
+      each_sample(r, [&](auto&& value, int t, bool exists) {
+        if (!exists || t < tA || t > tB) return;               // (uniform)
+        const double x = value();
+        const bool in = own && (t > tA || inA) && (t < tB || inB);
+        const double xm = in ? x : 0.0;
+        w1 += xm;
+        w2 = __builtin_fma(xm, xm, w2);
+      });
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      w1 += shfl_down_d(w1, o);
+      w2 += shfl_down_d(w2, o);
+    }
+    if (lane == 0) { wred[wave][r][0] = w1; wred[wave][r][1] = w2; }
+  }
+  __syncthreads();
+  if (tid < 2 && 2 * g + tid < rows) {
+    double w1 = 0, w2 = 0;
+    for (int w = 0; w < NW; ++w) { w1 += wred[w][tid][0]; w2 += wred[w][tid][1]; }
+    double* dst = fa.wsum + (size_t(2 * g + tid) * pa.splits + cb) * 2;
+    st_agent(dst, w1); st_agent(dst + 1, w2);
+  }
+  stores_done();                                               // this wavefront's stores (results, histogram windows, edge columns) have landed ...
+  __syncthreads();                                             // ... and so have the other wavefronts' before lane 0 announces the block
+  if (tid == 0) s_flag = atomicAdd(&fa.cnt[G + g], 1u) == unsigned(nblk - 1) ? 1 : 0;
+  __syncthreads();
+  stamp();                                                     // 5: window sums published
+  if (!s_flag) return;                                         // (uniform)
+
+  // ---- the last block of the transform finishes both rows
+  FinShared& fsh = *reinterpret_cast<FinShared*>(&hist[0][0]);
+#pragma nounroll
+  for (int r = 0; r < 2; ++r)
+    if (2 * g + r < rows) fin_row<LANES>(pa, fa, 2 * g + r, N1, N2, nch, fsh, tid);
+  stamp();                                                     // 6: both rows finished (last block only)
+  if (tid == 0) {                                              // every sibling is past both waits: the counters start the next launch at zero
+    __hip_atomic_store(&fa.cnt[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&fa.cnt[G + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace pal
