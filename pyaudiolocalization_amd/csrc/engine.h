@@ -51,6 +51,7 @@ struct Pfa {
   cd *rd_bhat_f = nullptr;   // forward direction (pfa_forward.h): FFT_L of exp(-2 pi i u2 g^s / N2) / L
   cd* rd_bhat = nullptr;     // 3-D spectrum of the Rader kernel sequence in prime-factor positions (mixed_radix.h)
   int *rd_qidx = nullptr, *rd_ridx = nullptr;
+  void* r89 = nullptr;       // N1 = 89: tables of the Rader column transform (pfa_rader89.h: Rader89Tab)
   int rows() const { return (n1 + 1) / 2; }   // spectrum rows k1 <= (N1-1)/2 kept by the permuted layout
   bool on() const { return n1 > 0; }
 };
@@ -182,6 +183,7 @@ struct Engine {
   bool fin_cols = false;      // PAL_FIN=1: the column pass finishes the rows itself without storing them (pfa_cols_fin.h) instead of storing the
                               // correlation rows for a finish launch (pfa_cols_stats.h).  Off by default: exact, 1.65 MB/pair of traffic instead of
                               // 2.38, but its cross-block wait and serial finish cost more time than the stores they save
+  bool allow_r89 = true;      // PAL_R89=0: dense 89-point column DFTs instead of Rader's 8 x 11 convolution (pfa_rader89.h)
   bool fuse_peaks = true;     // PAL_FUSED=0: separate column pass + pivot / stream launches instead of the fused column pass +
                               // peak statistics (pfa_cols_stats.h) where that applies
 };

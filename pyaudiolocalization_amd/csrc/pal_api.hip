@@ -267,6 +267,8 @@ int pal_create(int device, pal_handle* out) {
   if (env) e->pfa_forward = atoi(env) != 0;
   env = getenv("PAL_FUSED");
   if (env) e->fuse_peaks = atoi(env) != 0;
+  env = getenv("PAL_R89");
+  if (env) e->allow_r89 = atoi(env) != 0;
   env = getenv("PAL_FIN");
   if (env) e->fin_cols = atoi(env) != 0;
   env = getenv("PAL_PFA_SUB");

@@ -68,6 +68,7 @@ void Engine::free_pfa(Pfa& f) {
   if (f.r1) (void)hipFree(f.r1);
   if (f.T) (void)hipFree(f.T);
   if (f.rowtab) (void)hipFree(f.rowtab);
+  if (f.r89) (void)hipFree(f.r89);
   for (void* p : {(void*)f.rd_bhat, (void*)f.rd_bhat_f, (void*)f.rd_qidx,
                   (void*)f.rd_ridx})
     if (p) (void)hipFree(p);
@@ -167,6 +168,12 @@ int Engine::build_pfa(Plan& pl) {
   PAL_HIP(hipMemcpyAsync(f.T, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, stream));
   PAL_HIP(hipStreamSynchronize(stream));       // `tab` is host memory
   if (allow_rader && bn2 == 991) PAL_TRY(build_rader(f, n, u2 % bn2));   // 991 is prime and 990 = 11 x 9 x 10
+  if (allow_r89 && bn1 == kR89 && f.nch == 4) {                // the 89-point column DFT as Rader's 8 x 11 convolution (pfa_rader89.h)
+    Rader89Tab tab;
+    make_rader89_tab(tab);
+    PAL_HIP(hipMalloc(&f.r89, sizeof tab));
+    PAL_HIP(hipMemcpy(f.r89, &tab, sizeof tab, hipMemcpyHostToDevice));
+  }
   pl.pfa = f;
   return PAL_OK;
 }
@@ -350,7 +357,11 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
     const int nw = f.nch == 2 ? 2 : 4;                         // wavefronts per workgroup = chunks (three chunks: the fourth wavefront idles) or strips
 #define PAL_COLS_STATS(AD, FU, NW, ST) k_pfa_cols_stats<kPfaTC, kPfaUnr, AD, FU, NW, ST><<<grid, dim3(64 * NW), 0, on>>>(Y, corr, stride, f.n1, f.n2, G, f.nch, f.T, zero_rows, a, rows)
 #define PAL_COLS_STATS_NW(AD, FU) do { if (shortcols) PAL_COLS_STATS(AD, false, 4, true); else if (nw == 2) PAL_COLS_STATS(AD, FU, 2, false); else PAL_COLS_STATS(AD, FU, 4, false); } while (0)
-    if (adaptive) { if (full) PAL_COLS_STATS_NW(true, true); else PAL_COLS_STATS_NW(true, false); }
+    if (f.r89 && full && nw == 4 && !shortcols) {
+      const Rader89Tab* tab = static_cast<const Rader89Tab*>(f.r89);
+      if (adaptive) k_pfa_cols_stats<kPfaTC, kPfaUnr, true, true, 4, false, true><<<grid, dim3(256), 0, on>>>(Y, corr, stride, f.n1, f.n2, G, f.nch, f.T, zero_rows, a, rows, tab);
+      else k_pfa_cols_stats<kPfaTC, kPfaUnr, false, true, 4, false, true><<<grid, dim3(256), 0, on>>>(Y, corr, stride, f.n1, f.n2, G, f.nch, f.T, zero_rows, a, rows, tab);
+    } else if (adaptive) { if (full) PAL_COLS_STATS_NW(true, true); else PAL_COLS_STATS_NW(true, false); }
     else { if (full) PAL_COLS_STATS_NW(false, true); else PAL_COLS_STATS_NW(false, false); }
 #undef PAL_COLS_STATS_NW
 #undef PAL_COLS_STATS

@@ -34,6 +34,7 @@
 
 #include "peak_types.h"
 #include "pfa_kernels.h"
+#include "pfa_rader89.h"
 
 namespace pal {
 
@@ -65,11 +66,19 @@ __device__ __forceinline__ double min_raw(double a, double b) {
 // STRIPS = true (a short column DFT with a single chunk, N1 <= 23, e.g. 47 999 = 7 x 6857): they are NW neighbouring strips,
 // so that the block's histogram and window (fixed costs of a workgroup) are shared by NW x 62 columns instead of being
 // paid for 62 x N1 samples.
-template <int TC, int UNR, bool ADAPTIVE, bool FULL, int NW, bool STRIPS>
+// R89 (N1 = 89, four wavefronts): the column DFT is Rader's 8 x 11 convolution spread over the wavefronts (pfa_rader89.h)
+// instead of the dense form - half the arithmetic, a quarter of the loads; a wavefront then holds the output indices
+// tab->tmap[wave][.] (not a chunk in lag order: ties between equal samples are broken by their indices explicitly).
+template <int TC, int UNR, bool ADAPTIVE, bool FULL, int NW, bool STRIPS, bool R89 = false>
 __global__ __launch_bounds__(64 * NW) void k_pfa_cols_stats(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride, int N1, int N2,
                                                         int G, int nch, const double* __restrict__ T, const int* __restrict__ zero_rows, PeakArgs pa,
-                                                        int rows) {
-  __shared__ unsigned hist[2][kLogBins + 1];                  // + one dump bin for the lanes that own nothing
+                                                        int rows, const Rader89Tab* __restrict__ tab = nullptr) {
+  static_assert(!R89 || (NW == 4 && FULL && !STRIPS), "the Rader column transform is the four-wavefront N1 = 89 case");
+  // histograms of |x| (+ one dump bin for the lanes that own nothing); with R89 the same memory is first the exchange plane
+  // of the column transform (88 x 64 doubles)
+  constexpr int kHistDoubles = (2 * (kLogBins + 1) * int(sizeof(unsigned)) + 7) / 8;
+  __shared__ __attribute__((aligned(16))) double lds_big[R89 ? 88 * 64 : kHistDoubles];
+  unsigned (*const hist)[kLogBins + 1] = reinterpret_cast<unsigned (*)[kLogBins + 1]>(lds_big);
   __shared__ ColsWaveResult res[4][2];
   __shared__ double wmax[4][2];
   __shared__ unsigned wtot[4][2];
@@ -94,36 +103,57 @@ __global__ __launch_bounds__(64 * NW) void k_pfa_cols_stats(const cd* __restrict
   const int h = (N1 - 1) / 2;
   constexpr bool want_median = !ADAPTIVE;
   constexpr int LANES = 64 * NW;
-  if (want_median) {                                          // histograms of both rows start empty (the loads below are in flight meanwhile)
+  if (want_median && !R89) {                                  // histograms of both rows start empty (the loads below are in flight meanwhile)
     unsigned* hz = &hist[0][0];
     for (int q = tid; q < 2 * (kLogBins + 1); q += LANES) hz[q] = 0;
   }
-  double cx[TC], sy[TC], cy[TC], sx[TC];
+  constexpr int TCD = R89 ? 1 : TC;                            // (the dense form's accumulators do not exist in the Rader form)
+  double cx[TCD], sy[TCD], cy[TCD], sx[TCD];
   double sumx = 0, sumy = 0;
   cd y0 = mk(0, 0);
-  if (active) pfa_cols_accumulate<TC, UNR>(Yg, N1, N2, nch, ch, T, y0, cx, sy, cy, sx, sumx, sumy);
-  {   // a pair with a silent microphone: the row is exactly zero in the reference (see k_pfa_cols)
-    const double kp = zero_rows && zero_rows[2 * g] ? 0.0 : 1.0, kq = zero_rows && 2 * g + 1 < rows && zero_rows[2 * g + 1] ? 0.0 : 1.0;
+  cd ro[R89 ? kR89Slots : 1];                                  // Rader form: c[t] of the output indices tab->tmap[wave][.] (real part: pair p, imaginary part: pair q)
+  cd c0 = mk(0, 0);                                            //             and c[0] (wavefront 0)
+  const double kp = zero_rows && zero_rows[2 * g] ? 0.0 : 1.0, kq = zero_rows && 2 * g + 1 < rows && zero_rows[2 * g + 1] ? 0.0 : 1.0;
+  if constexpr (R89) {
+    r89_columns(Yg, N2, wave, lane, tab, lds_big, ro, c0);
+    if (want_median) {                                         // (the exchange plane is free now: it becomes the histograms)
+      unsigned* hz = &hist[0][0];
+      for (int q = tid; q < 2 * (kLogBins + 1); q += LANES) hz[q] = 0;
+    }
+    // a pair with a silent microphone: the row is exactly zero in the reference (see k_pfa_cols)
+    c0.x *= kp; c0.y *= kq;
+#pragma unroll
+    for (int i = 0; i < kR89Slots; ++i) { ro[i].x *= kp; ro[i].y *= kq; }
+  } else {
+    if (active) pfa_cols_accumulate<TC, UNR>(Yg, N1, N2, nch, ch, T, y0, cx, sy, cy, sx, sumx, sumy);
     if (kp == 0.0) { y0.x = sumx = 0.0; }
     if (kq == 0.0) { y0.y = sumy = 0.0; }
 #pragma unroll
-    for (int tt = 0; tt < TC; ++tt) {
+    for (int tt = 0; tt < TCD; ++tt) {
       cx[tt] *= kp; sy[tt] *= kp; cy[tt] *= kq; sx[tt] *= kq;
     }
   }
-  // the samples of this lane in lag order: t = 0 (chunk 0 only), the chunk ascending, the mirrors descending
-  auto each_sample = [&](int r, auto&& fn) {                   // fn(x, t, exists); `exists` is wave-uniform
-    const double base = r ? y0.y : y0.x;
-    fn(base + (r ? sumy : sumx), 0, ch == 0);
+  // the samples of this lane, fn(x, t, exists) with wave-uniform t and `exists`: in lag order for the dense form (t = 0 for
+  // chunk 0 only, the chunk ascending, the mirrors descending), in table order for the Rader form
+  auto each_sample = [&](int r, auto&& fn) {
+    if constexpr (R89) {
+      const auto* tm = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(&tab->tmap[wave][0]));
+      fn(r ? c0.y : c0.x, 0, wave == 0);
 #pragma unroll
-    for (int tt = 0; tt < TC; ++tt) {
-      const int t = ch * TC + tt + 1;
-      fn(r ? base + cy[tt] + sx[tt] : base + cx[tt] - sy[tt], t, FULL || t <= h);
-    }
+      for (int i = 0; i < kR89Slots; ++i) fn(r ? ro[i].y : ro[i].x, tm[i], true);
+    } else {
+      const double base = r ? y0.y : y0.x;
+      fn(base + (r ? sumy : sumx), 0, ch == 0);
 #pragma unroll
-    for (int tt = TC - 1; tt >= 0; --tt) {
-      const int t = ch * TC + tt + 1;
-      fn(r ? base + cy[tt] - sx[tt] : base + cx[tt] + sy[tt], N1 - t, FULL || t <= h);
+      for (int tt = 0; tt < TCD; ++tt) {
+        const int t = ch * TC + tt + 1;
+        fn(r ? base + cy[tt] + sx[tt] : base + cx[tt] - sy[tt], t, FULL || t <= h);
+      }
+#pragma unroll
+      for (int tt = TCD - 1; tt >= 0; --tt) {
+        const int t = ch * TC + tt + 1;
+        fn(r ? base + cy[tt] - sx[tt] : base + cx[tt] + sy[tt], N1 - t, FULL || t <= h);
+      }
     }
   };
   __syncthreads();                                             // the zeroed histograms are visible
@@ -241,11 +271,12 @@ __global__ __launch_bounds__(64 * NW) void k_pfa_cols_stats(const cd* __restrict
         out[N2 * t] = x;                                       // (border lanes store the value their column's owner stores)
         if (__ballot(x >= myfloor)) {
           const int m = m2 + N2 * t;
-          const bool up = own && x > vmax;
+          // (dense form: a lane meets its samples in lag order; Rader form: equal samples are ordered by their indices here)
+          const bool up = own && (x > vmax || (R89 && x == vmax && m < imax));
           vmax = up ? x : vmax;
           imax = up ? m : imax;
           const double left = from_lower_lane(x), right = from_upper_lane(x);
-          const bool cand = inner && x >= pfloor && x >= hb;
+          const bool cand = inner && x >= pfloor && (R89 ? (x > hb || (x == hb && m > mb)) : x >= hb);
           const bool pk = cand && left < x && right < x;
           hb = pk ? x : hb;
           mb = pk ? m : mb;

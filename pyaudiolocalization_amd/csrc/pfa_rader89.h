@@ -129,3 +129,79 @@ PAL_HD void r89_stage_c(cd* z0, cd* z1, int w) {
 }
 
 }  // namespace pal
+
+#ifdef __HIPCC__
+namespace pal {
+
+// The column transform of one workgroup (four wavefronts, lane = column): loads, stages A - C and the two exchanges.
+//   Yg     column of this lane: Yg[j * N2] = row j
+//   xch    LDS, 88 x 64 doubles: one plane of an exchange at a time
+//   out    [22]: c[t] for t = tab.tmap[w][i] (rows b8 = w: i < 11, b8 = w + 4: i >= 11); c0: c[0] (wavefront 0 only)
+// Every wavefront of the workgroup must call it (eight barriers inside).
+__device__ __forceinline__ void r89_columns(const cd* __restrict__ Yg, int N2, int w, int lane, const Rader89Tab* __restrict__ tab,
+                                            double* __restrict__ xch, cd* out, cd& c0) {
+  // wave-uniform tables through the scalar cache
+  const auto* rs = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(&tab->rowsel[w][0]));
+  const auto* Hs = reinterpret_cast<const __attribute__((address_space(4))) double*>(reinterpret_cast<uintptr_t>(&tab->H[w][0][0]));
+  cd v[22];
+#pragma unroll
+  for (int i = 0; i < 22; ++i) v[i] = Yg[size_t(rs[i]) * N2];           // all 22 rows in flight at once
+  const cd y0 = Yg[0];
+  r89_stage_a(v, v + 11, w);                                          // v[k11] = e, v[11 + k11] = o
+  // ---- exchange 1: wavefront w collects e, o of all four wavefronts at k11 = 3 w + q
+  cd e4[3][4], o4[3][4];
+  double* const mine = xch + lane;
+#pragma unroll
+  for (int plane = 0; plane < 2; ++plane) {
+#pragma unroll
+    for (int i = 0; i < 22; ++i) mine[((w * 2 + i / 11) * 11 + i % 11) * 64] = plane ? v[i].y : v[i].x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int k11 = 3 * w + q < 11 ? 3 * w + q : 10;                  // (wavefront 3 has two frequencies: the third slot repeats the last one, unused)
+#pragma unroll
+      for (int ws = 0; ws < 4; ++ws) {
+        const double a = mine[((ws * 2 + 0) * 11 + k11) * 64], b = mine[((ws * 2 + 1) * 11 + k11) * 64];
+        if (plane) { e4[q][ws].y = a; o4[q][ws].y = b; } else { e4[q][ws].x = a; o4[q][ws].x = b; }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- stage B
+  c0 = mk(0, 0);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    cd H8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) H8[k] = mk(Hs[(q * 8 + k) * 2], Hs[(q * 8 + k) * 2 + 1]);
+    cd c0q = mk(0, 0);
+    r89_stage_b(e4[q], o4[q], H8, q == 0 && w == 0, y0, c0q);
+    if (q == 0) c0 = c0q;
+  }
+  // ---- exchange 2: z0, z1 of row pair ws at k11 go back to wavefront ws
+#pragma unroll
+  for (int plane = 0; plane < 2; ++plane) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int k11 = 3 * w + q;
+      if (k11 < 11) {                                                    // (uniform)
+#pragma unroll
+        for (int ws = 0; ws < 4; ++ws) {
+          mine[((ws * 2 + 0) * 11 + k11) * 64] = plane ? e4[q][ws].y : e4[q][ws].x;
+          mine[((ws * 2 + 1) * 11 + k11) * 64] = plane ? o4[q][ws].y : o4[q][ws].x;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 22; ++i) {
+      const double a = mine[((w * 2 + i / 11) * 11 + i % 11) * 64];
+      if (plane) out[i].y = a; else out[i].x = a;
+    }
+    __syncthreads();
+  }
+  r89_stage_c(out, out + 11, w);
+}
+
+}  // namespace pal
+#endif

@@ -1,5 +1,7 @@
 """HIP engine (through the drop-in modules and the C ABI) against the oracle and the reference
 fixtures.  Integer outputs bit-exact; float outputs to the tolerance written at each assertion."""
+import os
+
 import numpy as np
 import pytest
 
@@ -234,9 +236,18 @@ def test_fused_column_pass_matches_separate_launches_and_oracle(engine, length, 
         assert "k_pfa_cols_stats" not in ent and ent["k_peak_stream"][1] >= 1, ent
     finally:
         plain.close()
-    assert np.array_equal(c1, c0)                               # the same FMAs in the same order
-    for name in ("k_sel", "branch", "k_argmax", "n_sel", "cmax", "cmin", "sel_height"):
-        assert np.array_equal(t1[name], t0[name]), name
+    if n1 == 89 and os.environ.get("PAL_R89", "1") != "0":
+        # 89-point columns: the fused pass runs Rader's 8 x 11 convolution (csrc/pfa_rader89.h), the separate column pass the
+        # dense form - other arithmetic, the same sequence to rounding (samples are below 1 in magnitude)
+        assert np.max(np.abs(c1 - c0)) <= 4e-15
+        for name in ("k_sel", "branch", "k_argmax", "n_sel"):
+            assert np.array_equal(t1[name], t0[name]), name
+        for name in ("cmax", "cmin", "sel_height"):
+            assert np.allclose(t1[name], t0[name], rtol=1e-12, atol=4e-15), name
+    else:
+        assert np.array_equal(c1, c0)                           # the same FMAs in the same order
+        for name in ("k_sel", "branch", "k_argmax", "n_sel", "cmax", "cmin", "sel_height"):
+            assert np.array_equal(t1[name], t0[name]), name
     assert np.allclose(t1["snr"], t0["snr"], rtol=1e-11, atol=0)   # sums with other shifts, added in another order
     for b in range(2):
         want = O.all_pairs(frames[b], fs, max_expected_delay=med, threshold_method=method)
