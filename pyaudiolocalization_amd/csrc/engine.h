@@ -183,6 +183,8 @@ struct Engine {
   bool fin_cols = false;      // PAL_FIN=1: the column pass finishes the rows itself without storing them (pfa_cols_fin.h) instead of storing the
                               // correlation rows for a finish launch (pfa_cols_stats.h).  Off by default: exact, 1.65 MB/pair of traffic instead of
                               // 2.38, but its cross-block wait and serial finish cost more time than the stores they save
+  unsigned fin_epoch[3] = {};   // launches of the finishing column pass per stream slot (pfa_cols_fin.h: validity tag of what its blocks exchange)
+  size_t fin_bytes[3] = {};
   bool allow_r89 = true;      // PAL_R89=0: dense 89-point column DFTs instead of Rader's 8 x 11 convolution (pfa_rader89.h)
   bool fuse_peaks = true;     // PAL_FUSED=0: separate column pass + pivot / stream launches instead of the fused column pass +
                               // peak statistics (pfa_cols_stats.h) where that applies

@@ -128,8 +128,6 @@ static int check_status(Engine* e) {
   if (st) {
     hipMemset(e->ws[7], 0, sizeof st);
     if (st & 4) {
-      for (int k = 16; k < 19; ++k)                            // arrival counters of the finishing column pass start every launch at zero
-        if (e->ws[k]) hipMemset(e->ws[k], 0, e->ws_bytes[k] < 8192 ? e->ws_bytes[k] : 8192);
       return e->fail(PAL_ERR_INTERNAL, "column pass: a workgroup gave up waiting for the other column blocks of its transform (the table of this call is not valid)");
     }
     return e->fail(PAL_ERR_INTERNAL, "peak selection: suppression chain exceeded the on-chip memo/stack (rows fell back to argmax)");

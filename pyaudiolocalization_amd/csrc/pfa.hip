@@ -386,10 +386,9 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
   const int n = pl.n;
   PeakArgs a;
   PAL_TRY(peaks_setup(nullptr, 0, rows, n, n2, prm, nblk, f.n2, on, a));
-  // per-stream scratch of the finishing pass: [counters 2 G | wsum | emax | parts | edge]
+  // per-stream scratch of the finishing pass: [done words G x blocks | emax | parts | edge]
   const int Gmax = pair_group(n);
-  const size_t off_wsum = (size_t(2 * Gmax) * sizeof(unsigned) + 127) & ~size_t(127);
-  const size_t off_emax = (off_wsum + size_t(2 * Gmax) * nblk * 2 * sizeof(double) + 127) & ~size_t(127);
+  const size_t off_emax = (size_t(Gmax) * nblk * sizeof(unsigned) + 127) & ~size_t(127);
   const size_t off_parts = (off_emax + size_t(2 * Gmax) * nblk * 8 * sizeof(double) + 127) & ~size_t(127);
   const size_t off_edge = (off_parts + size_t(2 * Gmax) * nblk * sizeof(FinPartial) + 127) & ~size_t(127);
   const size_t total = off_edge + size_t(2 * Gmax) * 4 * f.n1 * sizeof(double);
@@ -405,8 +404,14 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
   FinArgs fa;
   fa.table = table;
   fa.need = need;
-  fa.cnt = reinterpret_cast<unsigned*>(base);
-  fa.wsum = reinterpret_cast<double*>(base + off_wsum);
+  fa.done = reinterpret_cast<unsigned*>(base);
+  // launch number of this stream's scratch: entries of earlier launches fail the comparison (no resets, no counters)
+  if (ws_bytes[16 + slot] != fin_bytes[slot] || fin_epoch[slot] >= (1u << 20)) {     // new (zeroed) scratch, or the number would outgrow a double's integers
+    if (fin_epoch[slot] >= (1u << 20)) PAL_HIP(hipMemsetAsync(sp, 0, total, on));
+    fin_bytes[slot] = ws_bytes[16 + slot];
+    fin_epoch[slot] = 0;
+  }
+  fa.epoch = ++fin_epoch[slot];
   fa.emax = reinterpret_cast<double*>(base + off_emax);
   fa.parts = reinterpret_cast<FinPartial*>(base + off_parts);
   fa.edge = reinterpret_cast<double*>(base + off_edge);
@@ -430,6 +435,8 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
       fa.win_hi = int(hi > n - 2 ? n - 2 : hi);
     }
   }
+  static const bool no_cheb = getenv("PAL_FIN_HIST") != nullptr;    // diagnostics: histograms for every multiplier
+  fa.cheb = a.method == 0 && prm.threshold_multiplier >= 0 && prm.threshold_multiplier <= 2.0 && !no_cheb ? 1 : 0;
   fa.stamps = nullptr;
   static const bool want_stamps = getenv("PAL_DEBUG_STAMPS") != nullptr;
   const unsigned nwg = 8u * unsigned((G + 7) / 8) * unsigned(nblk);
@@ -444,11 +451,16 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
     ProfScope ps(this, "k_pfa_cols_fin", on);
     const dim3 grid(nwg);
     const bool full = (f.n1 - 1) / 2 == f.nch * kPfaTC;
-    const bool adaptive = a.method > 0;
+    // histograms only where the bound sqrt(2 mean(x^2)) on the median cannot decide: multipliers above 2 (or negative)
+    const bool adaptive = a.method > 0 || fa.cheb;             // (template flag: no histograms)
     const int nw = f.nch == 2 ? 2 : 4;
-#define PAL_COLS_FIN(AD, FU, NW) k_pfa_cols_fin<kPfaTC, kPfaUnr, AD, FU, NW><<<grid, dim3(64 * NW), 0, on>>>(Y, f.n1, f.n2, G, f.nch, nblk, f.T, zero_rows, a, fa, rows)
+#define PAL_COLS_FIN(AD, FU, NW) k_pfa_cols_fin<kPfaTC, kPfaUnr, !(AD), FU, NW><<<grid, dim3(64 * NW), 0, on>>>(Y, f.n1, f.n2, G, f.nch, nblk, f.T, zero_rows, a, fa, rows)
 #define PAL_COLS_FIN_NW(AD, FU) do { if (nw == 2) PAL_COLS_FIN(AD, FU, 2); else PAL_COLS_FIN(AD, FU, 4); } while (0)
-    if (adaptive) { if (full) PAL_COLS_FIN_NW(true, true); else PAL_COLS_FIN_NW(true, false); }
+    if (f.r89 && full && nw == 4) {
+      const Rader89Tab* tab = static_cast<const Rader89Tab*>(f.r89);
+      if (adaptive) k_pfa_cols_fin<kPfaTC, kPfaUnr, false, true, 4, true><<<grid, dim3(256), 0, on>>>(Y, f.n1, f.n2, G, f.nch, nblk, f.T, zero_rows, a, fa, rows, tab);
+      else k_pfa_cols_fin<kPfaTC, kPfaUnr, true, true, 4, true><<<grid, dim3(256), 0, on>>>(Y, f.n1, f.n2, G, f.nch, nblk, f.T, zero_rows, a, fa, rows, tab);
+    } else if (adaptive) { if (full) PAL_COLS_FIN_NW(true, true); else PAL_COLS_FIN_NW(true, false); }
     else { if (full) PAL_COLS_FIN_NW(false, true); else PAL_COLS_FIN_NW(false, false); }
 #undef PAL_COLS_FIN_NW
 #undef PAL_COLS_FIN

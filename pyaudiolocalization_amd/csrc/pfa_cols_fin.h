@@ -37,6 +37,7 @@
 
 #include "pfa_cols_stats.h"
 #include "reduce.h"
+#include "wave_reduce.h"
 
 namespace pal {
 
@@ -44,21 +45,23 @@ struct FinPartial {               // what one column block hands to the finishin
   double vmin, hb, plat;          // minimum; highest strict peak (mb = -1: none); highest sample with an equal neighbour (-inf: none)
   double s1, s2, a1;              // sum x, sum x^2, sum |x|
   double hw, platw;               // lag window: highest strict peak inside it (mw = -1: none), highest tie inside it
+  double w1, w2;                  // sum x, sum x^2 of the block's samples inside the SNR window around the row's maximum
   int mb, mw;
 };
-static_assert(sizeof(FinPartial) == 72, "nine words");
+static_assert(sizeof(FinPartial) == 88, "eleven words");
 
 struct FinArgs {
   pal_pair_record* table;         // [rows] records of this launch group
   int* need;                      // [rows] of this launch group inside the call-wide flag array: 1 = the pair goes through the stored-row path
-  unsigned* cnt;                  // [2 G] arrivals of the wavefronts' maxima / of the blocks' window sums (zero between launches)
+  unsigned* done;                 // [G][S] the launch number (`epoch`) once a block's results are complete
   double* edge;                   // [rows][4][N1] columns 0, 1, N2 - 2, N2 - 1 of the grid
-  double* wsum;                   // [rows][S][2] window sums of the blocks
-  double* emax;                   // [rows][S][4][2] every wavefront's (maximum, first index of it as a double), published behind pass A
+  double* emax;                   // [rows][S][4][2] every wavefront's (maximum, 2^32 epoch + 1 + first index of it), ONE 16-byte store behind pass A
+  unsigned epoch;                 // number of this launch on its stream (> 0; the scratch starts zeroed): stale entries fail the comparison, nothing is reset
   FinPartial* parts;              // [rows][S]
   int* status;                    // engine status words (bit 2 of word 0: a wait timed out; word 4: flagged rows)
   int win_lo, win_hi;             // lag window as sample indices, |m - (n2 - 1)| / fs <= max_expected_delay (win_lo > win_hi: empty)
   int windowed;
+  int cheb;                       // 1: no histograms - the median of |corr| is bounded by sqrt(2 mean(corr^2)) (see fin_row)
   unsigned long long* stamps;     // diagnostics (PAL_DEBUG_STAMPS=1): [workgroup][8] 100 MHz clock reads of lane 0 per phase
 };
 
@@ -73,12 +76,15 @@ struct FinShared {                // finishing block's scratch, laid over the hi
   FinWave wave[4];
 };
 static_assert(sizeof(FinShared) <= 2 * (kLogBins + 1) * sizeof(unsigned), "the finish scratch aliases the histograms");
+static_assert(alignof(FinShared) <= 16, "(the histograms' storage is 16-byte aligned)");
 
 // What the column blocks of a transform hand to each other travels in device-scope relaxed atomic stores and loads (sc1:
 // through the caches to the coherence point) - no release / acquire fences, which on this part write back and invalidate the
 // whole L2 (buffer_wbl2 / buffer_inv: eight of them per workgroup made this kernel five times slower than its arithmetic).
-// Order: a wavefront waits for its own stores (s_waitcnt vmcnt(0)) before it - or, behind a workgroup barrier, lane 0 - bumps
-// the counter; a reader sees the counter, passes a barrier, and only then issues its loads.
+// A device-scope store takes microseconds to be acknowledged, so nothing waits for one in the middle of a block's life: a
+// wavefront's (maximum, index) pair is ONE aligned 16-byte store whose second word carries the launch number (a reader polls
+// the entry until the number is this launch's); only at its very end a block waits for its stores (s_waitcnt vmcnt(0)),
+// passes a barrier and writes the launch number into its `done` word, which the transform's last block polls.
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent(const double* p) {
@@ -104,16 +110,21 @@ template <class T> __device__ __forceinline__ T ld_words(const T* src) {
   return v;
 }
 __device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// one lane waits until *p >= want (the others sit at the barrier behind it); false: gave up
-__device__ __forceinline__ bool spin_until(const unsigned* p, unsigned want, const int* status) {
-  for (int spins = 0; spins < (1 << 17); ++spins) {            // (a fraction of a second; siblings arrive within microseconds)
-    if (ld_agent(p) >= want) return true;
-    if ((spins & 255) == 255 && (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) return false;   // another block gave up: the call has failed
-    __builtin_amdgcn_s_sleep(4);
-  }
-  return false;
+typedef double pal_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_agent16(double* p, double a, double b) {                 // one aligned 16-byte store, device scope
+  const pal_d2 v = {a, b};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
+__device__ __forceinline__ void ld_agent16(const double* p, double& a, double& b) {
+  pal_d2 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  a = v.x; b = v.y;
+}
+constexpr double kEpochUnit = 4294967296.0;                    // 2^32: an entry's second word = epoch x 2^32 + (index + 1)
+
+// has another block given up waiting?  (then the call has failed and nobody waits any longer)
+__device__ __forceinline__ bool call_failed(const int* status) { return (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4) != 0; }
+constexpr int kSpinLimit = 1 << 16;                            // polls of a bounded wait (a fraction of a second; siblings arrive within microseconds)
 
 // ---- the finishing block: one row from the blocks' published results (all LANES lanes, uniform control flow) ----
 template <int LANES>
@@ -132,7 +143,7 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
     for (int q = tid; q < S * 4; q += LANES) {
       if ((q & 3) >= nch) continue;
       const double v = ld_agent(em + 2 * q);
-      const int i = int(ld_agent(em + 2 * q + 1));
+      const int i = int(ld_agent(em + 2 * q + 1) - double(fa.epoch) * kEpochUnit) - 1;      // (complete: every block of the transform is done)
       if (i >= 0 && i < n && (imax < 0 || arg_better<0>(v, i, vmax, imax))) { vmax = v; imax = i; }
     }
   }
@@ -142,8 +153,7 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
     if (pt.mb >= 0 && (mb < 0 || higher(pt.hb, pt.mb, hb, mb))) { hb = pt.hb; mb = pt.mb; }
     plat = fmax(plat, pt.plat);
     s1 += pt.s1; s2 += pt.s2; a1 += pt.a1;
-    w1 += ld_agent(fa.wsum + (size_t(row) * S + q) * 2);
-    w2 += ld_agent(fa.wsum + (size_t(row) * S + q) * 2 + 1);
+    w1 += pt.w1; w2 += pt.w2;
     if (windowed) {
       if (pt.mw >= 0 && (mw < 0 || higher(pt.hw, pt.mw, hw, mw))) { hw = pt.hw; mw = pt.mw; }
       platw = fmax(platw, pt.platw);
@@ -228,6 +238,13 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
     double va = (s2 - a1 * a1 / double(n)) / double(n);
     if (va < 0) va = 0;
     tlo = thi = pa.mult * (a1 / double(n) + sqrt(va));         // utils.py:147
+  } else if (fa.cheb) {
+    // No histograms: at most half of the samples can have x^2 >= 2 mean(x^2) (Markov), so median(|corr|) <= sqrt(2 s2 / n).
+    // A peak at or above mult x that bound passes the threshold of utils.py:145 for certain - and the highest peak of a PHAT
+    // row stands 3 to 4 sigma above a median of 0.67 sigma, the bound is 1.41 sigma.  A candidate below the bound is not
+    // decided here: the row is flagged and the stored-row path computes its exact median.
+    thi = pa.mult * sqrt(2.0 * s2 / double(n)) * (1.0 + 1e-12);
+    tlo = -INFINITY;
   } else {
     const unsigned r1 = unsigned((n - 1) / 2), r2 = unsigned(n / 2);
     const BlockHist* bh = pa.bh + size_t(row) * S;
@@ -333,17 +350,24 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
 
 // grid: 8 * ceil(G / 8) * nblk workgroups; index b -> XCD stream b & 7, slot b >> 3; the transforms g = x, x + 8, ... of stream x
 // take nblk consecutive slots each (siblings adjacent, one XCD's L2 behind them when G is a multiple of 8)
-template <int TC, int UNR, bool ADAPTIVE, bool FULL, int NW>
+// R89: the column DFT is Rader's 8 x 11 convolution over the four wavefronts (pfa_rader89.h) instead of the dense form
+// HIST: threshold method 'median' with a histogram window per block (a rigorous 0.5 % interval for the row's median); false:
+//       'adaptive', or 'median' bounded without histograms (FinArgs.cheb: multipliers up to 2)
+template <int TC, int UNR, bool HIST, bool FULL, int NW, bool R89 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) void k_pfa_cols_fin(const cd* __restrict__ Y, int N1, int N2, int G, int nch, int nblk,
                                                       const double* __restrict__ T, const int* __restrict__ zero_rows, PeakArgs pa,
-                                                      FinArgs fa, int rows) {
-  __shared__ unsigned hist[2][kLogBins + 1];
+                                                      FinArgs fa, int rows, const Rader89Tab* __restrict__ tab = nullptr) {
+  static_assert(!R89 || (NW == 4 && FULL), "the Rader column transform is the four-wavefront N1 = 89 case");
+  // histograms of |x| (+ one dump bin for the lanes that own nothing); with R89 the same memory is first the exchange plane of
+  // the column transform (88 x 64 doubles), and in the finishing block its scratch at the end
+  constexpr int kHistDoubles = (2 * (kLogBins + 1) * int(sizeof(unsigned)) + 7) / 8;
+  __shared__ __attribute__((aligned(16))) double lds_big[R89 ? 88 * 64 : kHistDoubles];
+  unsigned (*const hist)[kLogBins + 1] = reinterpret_cast<unsigned (*)[kLogBins + 1]>(lds_big);
   __shared__ FinPartial res[4][2];
   __shared__ double wmax[4][2];
   __shared__ unsigned wtot[4][2];
   __shared__ int medbin[2];
   __shared__ int s_imax[2];
-  __shared__ double wred[4][2][2];
   __shared__ int s_flag;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -367,40 +391,60 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
   const cd* Yg = Y + size_t(g) * N1 * N2 + m2c;
   const int h = (N1 - 1) / 2;
   const int n = pa.n;
-  constexpr bool want_median = !ADAPTIVE;
+  constexpr bool want_median = HIST;
   constexpr int LANES = 64 * NW;
-  if (want_median) {
+  if (want_median && !R89) {
     unsigned* hz = &hist[0][0];
     for (int q = tid; q < 2 * (kLogBins + 1); q += LANES) hz[q] = 0;
   }
-  double cx[TC], sy[TC], cy[TC], sx[TC];
+  constexpr int TCD = R89 ? 1 : TC;                            // (the dense form's accumulators do not exist in the Rader form)
+  double cx[TCD], sy[TCD], cy[TCD], sx[TCD];
   double sumx = 0, sumy = 0;
   cd y0 = mk(0, 0);
-  if (active) pfa_cols_accumulate<TC, UNR>(Yg, N1, N2, nch, ch, T, y0, cx, sy, cy, sx, sumx, sumy);
-  {
-    const double kp = zero_rows && zero_rows[2 * g] ? 0.0 : 1.0, kq = zero_rows && 2 * g + 1 < rows && zero_rows[2 * g + 1] ? 0.0 : 1.0;
+  cd ro[R89 ? kR89Slots : 1];                                  // Rader form: c[t] of the output indices tab->tmap[wave][.]
+  cd c0 = mk(0, 0);                                            //             and c[0] (wavefront 0)
+  const double kp = zero_rows && zero_rows[2 * g] ? 0.0 : 1.0, kq = zero_rows && 2 * g + 1 < rows && zero_rows[2 * g + 1] ? 0.0 : 1.0;
+  if constexpr (R89) {
+    r89_columns(Yg, N2, wave, lane, tab, lds_big, ro, c0);
+    if (want_median) {                                         // (the exchange plane is free now: it becomes the histograms)
+      unsigned* hz = &hist[0][0];
+      for (int q = tid; q < 2 * (kLogBins + 1); q += LANES) hz[q] = 0;
+    }
+    c0.x *= kp; c0.y *= kq;
+#pragma unroll
+    for (int i = 0; i < kR89Slots; ++i) { ro[i].x *= kp; ro[i].y *= kq; }
+  } else {
+    if (active) pfa_cols_accumulate<TC, UNR>(Yg, N1, N2, nch, ch, T, y0, cx, sy, cy, sx, sumx, sumy);
     if (kp == 0.0) { y0.x = sumx = 0.0; }
     if (kq == 0.0) { y0.y = sumy = 0.0; }
 #pragma unroll
-    for (int tt = 0; tt < TC; ++tt) {
+    for (int tt = 0; tt < TCD; ++tt) {
       cx[tt] *= kp; sy[tt] *= kp; cy[tt] *= kq; sx[tt] *= kq;
     }
   }
   stamp();                                                     // 1: accumulated
-  // the samples of this lane in lag order: t = 0 (chunk 0 only), the chunk ascending, the mirrors descending.
-  // fn(value, t, exists): `value()` forms the sample (two additions) only where it is wanted; t and `exists` are wave-uniform
+  // the samples of this lane, fn(value, t, exists): `value()` yields the sample (formed by two additions in the dense form, so
+  // only where it is wanted); t and `exists` are wave-uniform.  Dense form: lag order (t = 0 for chunk 0 only, the chunk
+  // ascending, the mirrors descending); Rader form: table order
   auto each_sample = [&](int r, auto&& fn) {
-    const double base = r ? y0.y : y0.x;
-    fn([&]() { return base + (r ? sumy : sumx); }, 0, ch == 0);
+    if constexpr (R89) {
+      const auto* tm = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(&tab->tmap[wave][0]));
+      fn([&]() { return r ? c0.y : c0.x; }, 0, wave == 0);
 #pragma unroll
-    for (int tt = 0; tt < TC; ++tt) {
-      const int t = ch * TC + tt + 1;
-      fn([&]() { return r ? base + cy[tt] + sx[tt] : base + cx[tt] - sy[tt]; }, t, FULL || t <= h);
-    }
+      for (int i = 0; i < kR89Slots; ++i) fn([&]() { return r ? ro[i].y : ro[i].x; }, tm[i], true);
+    } else {
+      const double base = r ? y0.y : y0.x;
+      fn([&]() { return base + (r ? sumy : sumx); }, 0, ch == 0);
 #pragma unroll
-    for (int tt = TC - 1; tt >= 0; --tt) {
-      const int t = ch * TC + tt + 1;
-      fn([&]() { return r ? base + cy[tt] - sx[tt] : base + cx[tt] + sy[tt]; }, N1 - t, FULL || t <= h);
+      for (int tt = 0; tt < TCD; ++tt) {
+        const int t = ch * TC + tt + 1;
+        fn([&]() { return r ? base + cy[tt] + sx[tt] : base + cx[tt] - sy[tt]; }, t, FULL || t <= h);
+      }
+#pragma unroll
+      for (int tt = TCD - 1; tt >= 0; --tt) {
+        const int t = ch * TC + tt + 1;
+        fn([&]() { return r ? base + cy[tt] - sx[tt] : base + cx[tt] + sy[tt]; }, N1 - t, FULL || t <= h);
+      }
     }
   };
   __syncthreads();
@@ -419,7 +463,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
       each_sample(r, [&](auto&& value, int t, bool exists) {
         if (!exists) return;
         const double x = value();
-        const bool up = x > vm;
+        const bool up = x > vm || (R89 && x == vm && t < tm);  // (Rader form: not in lag order - the smaller index of equal samples)
         vm = up ? x : vm;
         tm = up ? t : tm;
         vn = min_raw(vn, x);
@@ -435,30 +479,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
     }
     int im = own && vm > -INFINITY ? m2 + N2 * tm : -1;
     if (!own) { vm = -INFINITY; vn = INFINITY; s1 = s2 = a1 = 0; }
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ov = shfl_down_d(vm, o);
-      const int oi = __shfl_down(im, o, 64);
-      if (oi >= 0 && (im < 0 || arg_better<0>(ov, oi, vm, im))) { vm = ov; im = oi; }
-      vn = fmin(vn, shfl_down_d(vn, o));
-      s1 += shfl_down_d(s1, o);
-      s2 += shfl_down_d(s2, o);
-      a1 += shfl_down_d(a1, o);
-    }
-    if (lane == 0) {
-      wmax[wave][r] = vm;
+    wave_arg63(vm, im, [](double v1, int i1, double v2, int i2) { return arg_better<0>(v1, i1, v2, i2); });
+    vn = wave_min63(vn);
+    s1 = wave_sum63(s1);
+    s2 = wave_sum63(s2);
+    a1 = wave_sum63(a1);
+    if (lane == 63) {
+      wmax[wave][r] = im >= 0 ? vm : -INFINITY;
       FinPartial& w = res[wave][r];
       w.vmin = vn; w.s1 = s1; w.s2 = s2; w.a1 = a1;
-      // the wavefront's maximum and the first index of it go out NOW: the siblings need the row's argmax for their SNR window
-      // sums, and published here it has arrived by the time they are through their own pass B
-      if (active && r < nrow) {
-        double* dst = fa.emax + ((size_t(2 * g + r) * pa.splits + cb) * 4 + wave) * 2;
-        st_agent(dst, vm); st_agent(dst + 1, double(im));
-      }
+      // the wavefront's maximum and the first index of it go out NOW, in one 16-byte store that nobody waits for: the siblings
+      // need the row's argmax for their SNR window sums, and it has arrived by the time they are through their own pass B
+      if (active && r < nrow)
+        st_agent16(fa.emax + ((size_t(2 * g + r) * pa.splits + cb) * 4 + wave) * 2, vm, double(fa.epoch) * kEpochUnit + double(im + 1));
     }
-  }
-  if (active) {                                                // (uniform) one arrival per active wavefront
-    stores_done();
-    if (lane == 0) atomicAdd(&fa.cnt[g], 1u);
   }
   __syncthreads();
   // ---- the block's median bin per row, then the window around it is published
@@ -555,7 +589,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
           if (__ballot(x >= myfloor)) {
             const int m = m2 + N2 * t;
             const double left = from_lower_lane(x), right = from_upper_lane(x);
-            const bool cand = inner && x >= pfloor && x >= hb;
+            const bool cand = inner && x >= pfloor && (R89 ? (x > hb || (x == hb && m > mb)) : x >= hb);
             const bool pk = cand && left < x && right < x;
             hb = pk ? x : hb;
             mb = pk ? m : mb;
@@ -563,13 +597,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
           }
         });
       }
-      for (int o = 32; o > 0; o >>= 1) {
-        const double hv = shfl_down_d(hb, o);
-        const int hi_ = __shfl_down(mb, o, 64);
-        if (hi_ >= 0 && (mb < 0 || higher(hv, hi_, hb, mb))) { hb = hv; mb = hi_; }
-        plat = fmax(plat, shfl_down_d(plat, o));
-      }
-      if (lane == 0) {
+      wave_arg63(hb, mb, [](double v1, int i1, double v2, int i2) { return higher(v1, i1, v2, i2); });
+      plat = wave_max63(plat);
+      if (lane == 63) {
         FinPartial& w = res[wave][r];
         w.hb = hb; w.plat = plat; w.mb = mb;
       }
@@ -587,16 +617,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
             const double left = from_lower_lane(x), right = from_upper_lane(x);
             const bool in = inner && m >= lo1 && m <= hi1;
             platw = in && (left == x || right == x) ? fmax(platw, x) : platw;
-            if (in && left < x && right < x && x >= hq) { hq = x; mq = m; }
+            if (in && left < x && right < x && (R89 ? (x > hq || (x == hq && m > mq)) : x >= hq)) { hq = x; mq = m; }
           });
         }
-        for (int o = 32; o > 0; o >>= 1) {
-          const double v = shfl_down_d(hq, o);
-          const int i = __shfl_down(mq, o, 64);
-          if (i >= 0 && (mq < 0 || higher(v, i, hq, mq))) { hq = v; mq = i; }
-          platw = fmax(platw, shfl_down_d(platw, o));
-        }
-        if (lane == 0) {
+        wave_arg63(hq, mq, [](double v1, int i1, double v2, int i2) { return higher(v1, i1, v2, i2); });
+        platw = wave_max63(platw);
+        if (lane == 63) {
           FinPartial& w = res[wave][r];
           w.hw = hq; w.mw = mq; w.platw = platw;
         }
@@ -615,55 +641,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
     if (!again) break;                                         // (uniform: every lane read the same LDS words)
     __syncthreads();
   }
-  // ---- publish: lanes 0 / 1 merge the wavefronts of row p / q
-  if (tid < 2 && 2 * g + tid < rows) {
-    const int r = tid, row = 2 * g + r;
-    FinPartial pt;
-    pt.hb = pt.plat = pt.platw = -INFINITY;
-    pt.vmin = INFINITY;
-    pt.mb = pt.mw = -1;
-    pt.s1 = pt.s2 = pt.a1 = pt.hw = 0;
-    for (int w = 0; w < NW; ++w) {
-      const FinPartial x = res[w][r];
-      pt.vmin = fmin(pt.vmin, x.vmin);
-      if (x.mb >= 0 && (pt.mb < 0 || higher(x.hb, x.mb, pt.hb, pt.mb))) { pt.hb = x.hb; pt.mb = x.mb; }
-      pt.s1 += x.s1; pt.s2 += x.s2; pt.a1 += x.a1;
-      pt.plat = fmax(pt.plat, x.plat);
-      if (windowed) {
-        if (x.mw >= 0 && (pt.mw < 0 || higher(x.hw, x.mw, pt.hw, pt.mw))) { pt.hw = x.hw; pt.mw = x.mw; }
-        pt.platw = fmax(pt.platw, x.platw);
-      }
-    }
-    st_words(fa.parts + size_t(row) * pa.splits + cb, pt);
-  }
-
   // ---- phase 2: the siblings' maxima (published long ago), then the SNR window sums of this block's samples
-  stamp();                                                     // 3: pass B, published
-  if (tid == 0) {
-    s_flag = spin_until(&fa.cnt[g], unsigned(nblk * nch), fa.status) ? 0 : 1;
-    if (s_flag) atomicOr(fa.status, 4);
-  }
-  __syncthreads();
-  stamp();                                                     // 4: the siblings' maxima have arrived
+  stamp();                                                     // 3: pass B
   if (wave < 2 && 2 * g + wave < rows) {
     const int row = 2 * g + wave;
     double bv = 0;
     int bi = -1;
     const double* em = fa.emax + size_t(row) * pa.splits * 8;
-    for (int q = lane; q < pa.splits * 4; q += 64) {           // (entry = block * 4 + wavefront; idle wavefronts never wrote theirs)
+    const double want = double(fa.epoch);
+    bool late = false;
+    for (int q = lane; q < pa.splits * 4; q += 64) {           // (entry = block * 4 + wavefront; idle wavefronts never write theirs)
       if ((q & 3) >= nch) continue;
-      const double v = ld_agent(em + 2 * q);
-      const int i = int(ld_agent(em + 2 * q + 1));
-      if (i >= 0 && i < n && (bi < 0 || arg_better<0>(v, i, bv, bi))) { bv = v; bi = i; }
+      double v = 0, code = 0;
+      int spins = 0;
+      for (;;) {                                               // (the entry of this launch: its second word carries the launch number)
+        ld_agent16(em + 2 * q, v, code);
+        if (floor(code / kEpochUnit) == want) break;
+        if (++spins > kSpinLimit || ((spins & 255) == 0 && call_failed(fa.status))) { late = true; break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      const int i = int(code - want * kEpochUnit) - 1;
+      if (!late && i >= 0 && i < n && (bi < 0 || arg_better<0>(v, i, bv, bi))) { bv = v; bi = i; }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ov = shfl_down_d(bv, o);
-      const int oi = __shfl_down(bi, o, 64);
-      if (oi >= 0 && (bi < 0 || arg_better<0>(ov, oi, bv, bi))) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) s_imax[wave] = bi;
+    if (__ballot(late) && lane == 0) atomicOr(fa.status, 4);
+    wave_arg63(bv, bi, [](double v1, int i1, double v2, int i2) { return arg_better<0>(v1, i1, v2, i2); });
+    if (lane == 63) s_imax[wave] = bi;
   }
   __syncthreads();
+  stamp();                                                     // 4: the row's argmax is known
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     if (2 * g + r >= rows) continue;
@@ -683,36 +688,55 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
         w2 = __builtin_fma(xm, xm, w2);
       });
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      w1 += shfl_down_d(w1, o);
-      w2 += shfl_down_d(w2, o);
-    }
-    if (lane == 0) { wred[wave][r][0] = w1; wred[wave][r][1] = w2; }
+    w1 = wave_sum63(w1);
+    w2 = wave_sum63(w2);
+    if (lane == 63) { res[wave][r].w1 = w1; res[wave][r].w2 = w2; }
   }
   __syncthreads();
+  // ---- publish: lanes 0 / 1 merge the wavefronts of row p / q; then the block is done
   if (tid < 2 && 2 * g + tid < rows) {
-    double w1 = 0, w2 = 0;
-    for (int w = 0; w < NW; ++w) { w1 += wred[w][tid][0]; w2 += wred[w][tid][1]; }
-    double* dst = fa.wsum + (size_t(2 * g + tid) * pa.splits + cb) * 2;
-    st_agent(dst, w1); st_agent(dst + 1, w2);
+    const int r = tid, row = 2 * g + r;
+    FinPartial pt;
+    pt.hb = pt.plat = pt.platw = -INFINITY;
+    pt.vmin = INFINITY;
+    pt.mb = pt.mw = -1;
+    pt.s1 = pt.s2 = pt.a1 = pt.hw = pt.w1 = pt.w2 = 0;
+    for (int w = 0; w < NW; ++w) {
+      const FinPartial x = res[w][r];
+      pt.vmin = fmin(pt.vmin, x.vmin);
+      if (x.mb >= 0 && (pt.mb < 0 || higher(x.hb, x.mb, pt.hb, pt.mb))) { pt.hb = x.hb; pt.mb = x.mb; }
+      pt.s1 += x.s1; pt.s2 += x.s2; pt.a1 += x.a1; pt.w1 += x.w1; pt.w2 += x.w2;
+      pt.plat = fmax(pt.plat, x.plat);
+      if (windowed) {
+        if (x.mw >= 0 && (pt.mw < 0 || higher(x.hw, x.mw, pt.hw, pt.mw))) { pt.hw = x.hw; pt.mw = x.mw; }
+        pt.platw = fmax(pt.platw, x.platw);
+      }
+    }
+    st_words(fa.parts + size_t(row) * pa.splits + cb, pt);
   }
   stores_done();                                               // this wavefront's stores (results, histogram windows, edge columns) have landed ...
   __syncthreads();                                             // ... and so have the other wavefronts' before lane 0 announces the block
-  if (tid == 0) s_flag = atomicAdd(&fa.cnt[G + g], 1u) == unsigned(nblk - 1) ? 1 : 0;
-  __syncthreads();
-  stamp();                                                     // 5: window sums published
-  if (!s_flag) return;                                         // (uniform)
+  if (tid == 0) st_agent(fa.done + size_t(g) * nblk + cb, fa.epoch);
+  stamp();                                                     // 5: published
+  if (cb != nblk - 1) return;                                  // (uniform)
 
-  // ---- the last block of the transform finishes both rows
-  FinShared& fsh = *reinterpret_cast<FinShared*>(&hist[0][0]);
+  // ---- the last block of the transform waits for its siblings' results and finishes both rows
+  {
+    bool late = false;
+    for (int q = tid; q < nblk - 1; q += LANES) {
+      int spins = 0;
+      while (ld_agent(fa.done + size_t(g) * nblk + q) != fa.epoch) {
+        if (++spins > kSpinLimit || ((spins & 255) == 0 && call_failed(fa.status))) { late = true; break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    if (__syncthreads_or(late ? 1 : 0) && tid == 0) atomicOr(fa.status, 4);
+  }
+  FinShared& fsh = *reinterpret_cast<FinShared*>(lds_big);
 #pragma nounroll
   for (int r = 0; r < 2; ++r)
     if (2 * g + r < rows) fin_row<LANES>(pa, fa, 2 * g + r, N1, N2, nch, fsh, tid);
   stamp();                                                     // 6: both rows finished (last block only)
-  if (tid == 0) {                                              // every sibling is past both waits: the counters start the next launch at zero
-    __hip_atomic_store(&fa.cnt[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&fa.cnt[G + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 }  // namespace pal

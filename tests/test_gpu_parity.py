@@ -272,8 +272,12 @@ def test_fused_column_pass_plateaus_and_grid_edges(engine, monkeypatch):
         t0 = plain.gcc_phat_all_pairs(frames, 8000.0)
     finally:
         plain.close()
-    for name in ("k_sel", "branch", "k_argmax", "n_sel", "cmax", "cmin", "sel_height"):
+    for name in ("k_sel", "branch", "k_argmax", "n_sel"):
         assert np.array_equal(t1[name], t0[name]), name
+    for name in ("cmax", "cmin", "sel_height"):
+        # (the column pass that finishes its rows itself, PAL_FIN=1, sends rows with ties through the stored-row path at the end of
+        #  the call, packed with another partner pair: last-bit differences)
+        assert np.allclose(t1[name], t0[name], rtol=1e-12, atol=4e-15), name
     for b in range(3):
         want = O.all_pairs(frames[b], 8000.0)
         for name in ("k_sel", "branch", "k_argmax"):
