@@ -69,7 +69,9 @@ struct Plan {
   long long used = 0;   // Engine::plan_clock at the last get_plan (the cache evicts the least recently used plan)
   // elements per row of the spectra that forward_spectra writes and pair_correlations reads: the half spectrum, or
   // the permuted rows k1 <= (N1-1)/2 of the prime-factor layout
-  size_t spec_stride() const { return pfa.on() ? size_t(pfa.rows()) * size_t(pfa.n2) : size_t(H); }
+  // (plans with Rader rows keep UNIT phasors S / |S| there and, behind them, a plane of doubles 1e-5 / |S|: conv_kernels.h whiten_unit)
+  size_t spec_points() const { return size_t(pfa.rows()) * size_t(pfa.n2); }
+  size_t spec_stride() const { return pfa.on() ? (pfa.rader ? spec_points() + (spec_points() + 1) / 2 : spec_points()) : size_t(H); }
 };
 
 struct ProfileSlot {
@@ -180,9 +182,8 @@ struct Engine {
   bool pfa_forward_applies(const Plan& pl, int len) const;
   int pfa_forward_spectra(Plan& pl, const double* frames, size_t frame_stride, int rows, int len, cd* spectra);
   bool pfa_forward = true;    // PAL_PFA_FWD=0: forward spectra on the four-step route even where the prime-factor cut applies
-  bool fin_cols = false;      // PAL_FIN=1: the column pass finishes the rows itself without storing them (pfa_cols_fin.h) instead of storing the
-                              // correlation rows for a finish launch (pfa_cols_stats.h).  Off by default: exact, 1.65 MB/pair of traffic instead of
-                              // 2.38, but its cross-block wait and serial finish cost more time than the stores they save
+  bool fin_cols = true;       // PAL_FIN=0: the fused column pass always stores the correlation rows for a finish launch (pfa_cols_stats.h) instead
+                              // of finishing the rows itself without storing them (pfa_cols_fin.h: one peak per row, nobody asks for `corr`)
   unsigned fin_epoch[3] = {};   // launches of the finishing column pass per stream slot (pfa_cols_fin.h: validity tag of what its blocks exchange)
   size_t fin_bytes[3] = {};
   bool allow_r89 = true;      // PAL_R89=0: dense 89-point column DFTs instead of Rader's 8 x 11 convolution (pfa_rader89.h)
