@@ -122,29 +122,17 @@ struct PermSpectrumStorer {
   float inv1, inv2;
   const cd* w;
   const int* slot;   // column k2 -> position inside a row (Rader rows keep generator order, pfa_rader.h); null: k2 itself
-  size_t stride;     // elements (cd) per microphone; with `slot` the rows hold unit phasors and a plane of 1e-5 / |S| follows them
   __device__ void operator()(int g, unsigned j, cd y) const {
     if (j >= (unsigned)H) return;
-    cd v = cmulc(y, w[j]);
-    double hv = 0;
-    if (slot) unit_phasor(v, v, hv);
+    const cd v = cmulc(y, w[j]);
     int k1 = int(j) - int(unsigned(float(j) * inv1)) * N1;      // j < 2^24: the float quotient is off by at most one
     k1 = k1 < 0 ? k1 + N1 : (k1 >= N1 ? k1 - N1 : k1);
     int k2 = int(j) - int(unsigned(float(j) * inv2)) * N2;
     k2 = k2 < 0 ? k2 + N2 : (k2 >= N2 ? k2 - N2 : k2);
-    cd* base = SP + size_t(g) * stride;
-    double* hbase = reinterpret_cast<double*>(base + size_t(NR) * N2);
+    cd* base = SP + size_t(g) * NR * N2;
     const int km = k2 ? N2 - k2 : 0;
-    if (k1 < NR) {
-      const size_t at = size_t(k1) * N2 + (slot ? slot[k2] : k2);
-      base[at] = v;
-      if (slot) hbase[at] = hv;
-    }
-    if (k1 == 0 ? j != 0 : k1 >= NR) {
-      const size_t at = size_t(k1 ? N1 - k1 : 0) * N2 + (slot ? slot[km] : km);
-      base[at] = cconj(v);
-      if (slot) hbase[at] = hv;
-    }
+    if (k1 < NR) base[size_t(k1) * N2 + (slot ? slot[k2] : k2)] = v;
+    if (k1 == 0 ? j != 0 : k1 >= NR) base[size_t(k1 ? N1 - k1 : 0) * N2 + (slot ? slot[km] : km)] = cconj(v);
   }
 };
 
@@ -506,7 +494,7 @@ int Engine::forward_spectra(Plan& pl, const double* frames, size_t frame_stride,
     if (pl.pfa.on()) {   // the prime-factor inverse reads the permuted layout (spec_stride() elements per row)
       const Pfa& f = pl.pfa;
       PermSpectrumStorer st{spectra + size_t(r0) * pl.spec_stride(), pl.H, f.n1, f.n2, f.rows(), 1.0f / float(f.n1),
-                            1.0f / float(f.n2), pl.w, f.rader ? f.rd_qidx : nullptr, pl.spec_stride()};
+                            1.0f / float(f.n2), pl.w, f.rader ? f.rd_qidx : nullptr};
       PAL_TRY(launch_cols_inv(e, c, G, W, st));
     } else {
       SpectrumStorer st{spectra + size_t(r0) * pl.H, pl.H, pl.w};

@@ -67,36 +67,6 @@ __device__ __forceinline__ cd whiten(cd a, cd b) {
   return mk(r.x * inv, r.y * inv);
 }
 
-// The same from per-microphone unit phasors.  With u = S / |S| and h = 1e-5 / |S| (both made once per microphone and bin by
-// the forward transform, unit_phasor below) the whitened cross spectrum of utils.py:116-117 is
-//     R = S_a conj(S_b) / (|S_a||S_b| + 1e-10) = u_a conj(u_b) / (1 + q),   q = h_a h_b = 1e-10 / (|S_a||S_b|).
-// For real recordings q is 1e-14 or so and 1 / (1 + q) = 1 - q + q^2 to rounding: nine operations per pair and bin instead of
-// the twenty-five of whiten() (square root, reciprocal and their Newton steps), a sixth of the row pass's vector
-// instructions.  Bins where q >= 1e-8 (a spectrum magnitude under 1e-2) take the exact reciprocal; a silent bin (|S| = 0:
-// u = 0, h = 0) gives R = 0 like the reference.
-__device__ __forceinline__ cd whiten_unit(cd ua, cd ub, double ha, double hb) {
-  const cd r = cmulc(ua, ub);
-  const double q = ha * hb;
-  double f = 1.0 + __builtin_fma(q, q, -q);
-  if (__builtin_expect(__ballot(q >= 1e-8) != 0, 0)) {        // (uniform; rare)
-    const double d = 1.0 + q;
-    double inv = __builtin_amdgcn_rcp(d);
-    inv = inv * __builtin_fma(-d, inv, 2.0);
-    inv = inv * __builtin_fma(-d, inv, 2.0);
-    f = q >= 1e-8 ? inv : f;
-  }
-  return mk(r.x * f, r.y * f);
-}
-__device__ __forceinline__ void unit_phasor(cd s, cd& u, double& h) {
-  const double m2 = __builtin_fma(s.x, s.x, s.y * s.y);
-  double y = __builtin_amdgcn_rsq(m2);
-  y = y * __builtin_fma(-0.5 * m2 * y, y, 1.5);
-  y = y * __builtin_fma(-0.5 * m2 * y, y, 1.5);
-  const bool ok = m2 > 0 && y < __builtin_huge_val();           // (|S| = 0, or so small that its square underflows: silent)
-  u = ok ? mk(s.x * y, s.y * y) : mk(0, 0);
-  h = ok ? 1e-5 * y : 0.0;
-}
-
 // ------------------------------------------------------------------ stage sources / sinks
 template <int L2> struct RowsGlobal {             // tile of 4096 consecutive points = 4096 / 2^L2 rows
   static constexpr bool kLds = false;

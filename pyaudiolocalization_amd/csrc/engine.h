@@ -69,9 +69,7 @@ struct Plan {
   long long used = 0;   // Engine::plan_clock at the last get_plan (the cache evicts the least recently used plan)
   // elements per row of the spectra that forward_spectra writes and pair_correlations reads: the half spectrum, or
   // the permuted rows k1 <= (N1-1)/2 of the prime-factor layout
-  // (plans with Rader rows keep UNIT phasors S / |S| there and, behind them, a plane of doubles 1e-5 / |S|: conv_kernels.h whiten_unit)
-  size_t spec_points() const { return size_t(pfa.rows()) * size_t(pfa.n2); }
-  size_t spec_stride() const { return pfa.on() ? (pfa.rader ? spec_points() + (spec_points() + 1) / 2 : spec_points()) : size_t(H); }
+  size_t spec_stride() const { return pfa.on() ? size_t(pfa.rows()) * size_t(pfa.n2) : size_t(H); }
 };
 
 struct ProfileSlot {

@@ -256,7 +256,7 @@ int Engine::pfa_rows(const Plan& pl, const cd* permuted, const int4* quads, int 
   const cd* tws = f.lm >= 11 ? stage_table_compact(f.lm) : stage_table(f.lm);
   if (f.rader) {
     ProfScope ps(this, "k_pfa_rows_rader<11,9,10>", on);
-    PfaRaderArgs a{permuted, pl.spec_stride(), quads, Y, f.rd_bhat, f.r1, f.rd_ridx, f.rowtab,
+    PfaRaderArgs a{permuted, quads, Y, f.rd_bhat, f.r1, f.rd_ridx, f.rowtab,
                    f.n1, f.n2, f.rows(), G, 1.0f / float(f.n1), 1.0 / double(pl.n), nullptr, xcd_rows};
     k_pfa_rows_rader<11, 9, 10><<<dim3(row_work_grid(G, f.rows(), xcd_rows)), dim3(256), 0, on>>>(a);
     PAL_HIP(hipGetLastError());
@@ -321,7 +321,7 @@ int Engine::pfa_forward_spectra(Plan& pl, const double* frames, size_t frame_str
     {
       ProfScope ps(this, "k_pfa_fwd_rows_rader<11,9,10>", stream);
       const PfaFwdRowsArgs a{Y, spectra + size_t(r0) * pl.spec_stride(), f.rd_bhat_f, f.r1,
-                             f.rd_qidx, f.rowtab, f.n1, f.n2, f.rows(), G, R, 1.0f / float(f.n1), pl.spec_stride()};
+                             f.rd_qidx, f.rowtab, f.n1, f.n2, f.rows(), G, R, 1.0f / float(f.n1)};
       k_pfa_fwd_rows_rader<11, 9, 10><<<dim3(unsigned(G) * unsigned(f.rows())), dim3(256), 0, stream>>>(a);
       PAL_HIP(hipGetLastError());
     }

@@ -110,7 +110,6 @@ struct PfaFwdRowsArgs {
   const int2* rowtab;    // per row of Y: (u1 row mod N1, -)
   int N1, N2, NR, G, rows;
   float inv;             // 1 / N1
-  size_t mic;            // elements (cd) per microphone: NR x N2 unit phasors, then the plane of 1e-5 / |S| (doubles)
 };
 
 // grid = G * NR workgroups of 256 lanes: rows k1 (tile 0) and N1 - k1 (tile 1) of one packed transform.
@@ -177,11 +176,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   const cd x0 = dc[0], z0 = dc[1];
   const cd sum0 = total[0] + x0, sum1 = total[1] + z0;
   const bool second = 2 * g + 1 < a.rows;
-  const size_t mic = a.mic;
+  const size_t mic = size_t(a.NR) * N2;
   cd* Sa = a.SP + size_t(2 * g) * mic + size_t(k1) * N2;
   cd* Sb = Sa + mic;
-  double* Ha = reinterpret_cast<double*>(a.SP + size_t(2 * g) * mic + size_t(a.NR) * N2) + size_t(k1) * N2;
-  double* Hb = reinterpret_cast<double*>(a.SP + size_t(2 * g + 1) * mic + size_t(a.NR) * N2) + size_t(k1) * N2;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int p = tid + 256 * u;
@@ -199,15 +196,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
         Z0 = sum0;
         Z1 = sum1;
       }
-      // the rows keep unit phasors and 1e-5 / |S| (whiten_unit, conv_kernels.h)
-      cd u;
-      double hv;
-      unit_phasor(mk(0.5 * (Z0.x + Z1.x), 0.5 * (Z0.y - Z1.y)), u, hv);   // (Z + conj Z') / 2
-      Sa[p] = u; Ha[p] = hv;
-      if (second) {
-        unit_phasor(mk(0.5 * (Z0.y + Z1.y), 0.5 * (Z1.x - Z0.x)), u, hv);   // (Z - conj Z') / 2i
-        Sb[p] = u; Hb[p] = hv;
-      }
+      Sa[p] = mk(0.5 * (Z0.x + Z1.x), 0.5 * (Z0.y - Z1.y));   // (Z + conj Z') / 2
+      if (second) Sb[p] = mk(0.5 * (Z0.y + Z1.y), 0.5 * (Z1.x - Z0.x));   // (Z - conj Z') / 2i
     }
   }
 }

@@ -25,9 +25,7 @@
 namespace pal {
 
 struct PfaRaderArgs {
-  const cd* SP;          // permuted spectra [mic][NR][N2] as UNIT phasors S / |S|, rows in generator order: x[g^-s] at pos(s), x[0] at L;
-                         // behind a microphone's NR x N2 phasors: the same positions of 1e-5 / |S| as doubles (whiten_unit)
-  size_t mic;            // elements (cd) per microphone
+  const cd* SP;          // permuted spectra [mic][NR][N2], rows in generator order: x[g^-s] at pos(s), x[0] at L
   const int4* quad;      // mic rows (a, b) of pair p and (c, d) of pair q; c < 0: no second pair
   cd* Y;                 // [G][N1][N2]
   const cd* bhat;        // 3-D spectrum of w^(g^s) in prime-factor positions, scaled by 1 / (L n)
@@ -120,16 +118,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   // ---- the first forward stage straight from global memory
   const auto* qp = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(a.quad)) + 4 * g;
   const int4 q = make_int4(qp[0], qp[1], qp[2], qp[3]);
-  const size_t mic = a.mic, off = size_t(k1) * N2, hoff = size_t(a.NR) * N2 * 2;   // (the plane of doubles starts behind the phasors)
+  const size_t mic = size_t(a.NR) * N2, off = size_t(k1) * N2;
   const bool second = q.z >= 0;
   const cd* sa = a.SP + size_t(q.x) * mic + off;
   const cd* sb = a.SP + size_t(q.y) * mic + off;
   const cd* sc = second ? a.SP + size_t(q.z) * mic + off : sa;
   const cd* sd = second ? a.SP + size_t(q.w) * mic + off : sb;
-  const double* ha = reinterpret_cast<const double*>(a.SP + size_t(q.x) * mic) + hoff + off;
-  const double* hb = reinterpret_cast<const double*>(a.SP + size_t(q.y) * mic) + hoff + off;
-  const double* hc = second ? reinterpret_cast<const double*>(a.SP + size_t(q.z) * mic) + hoff + off : ha;
-  const double* hd = second ? reinterpret_cast<const double*>(a.SP + size_t(q.w) * mic) + hoff + off : hb;
   const double keep2 = second ? 1.0 : 0.0;
   int ri[4];
 #pragma unroll
@@ -145,19 +139,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     const int upper = (tid >> 5) & 1, bf = 32 * (tid >> 6) + (tid & 31);
     const int bfc = bf < NB1 ? bf : NB1 - 1;
     cd va[HR], vb[HR], vc[HR], vd[HR];
-    double wa[HR], wb[HR], wc[HR], wd[HR];
 #pragma unroll
     for (int u = 0; u < HR; ++u) {
       const int j = upper * HR + u;
       const int at = bfc + NB1 * (j < R1 ? j : R1 - 1);
       va[u] = sa[at]; vb[u] = sb[at]; vc[u] = sc[at]; vd[u] = sd[at];
-      wa[u] = ha[at]; wb[u] = hb[at]; wc[u] = hc[at]; wd[u] = hd[at];
     }
     cd v[2 * HR];
 #pragma unroll
     for (int u = 0; u < HR; ++u) {
-      const cd r1 = whiten_unit(va[u], vb[u], wa[u], wb[u]);
-      const cd r2 = cscale(whiten_unit(vc[u], vd[u], wc[u], wd[u]), keep2);
+      const cd r1 = whiten(va[u], vb[u]);
+      const cd r2 = cscale(whiten(vc[u], vd[u]), keep2);
       const cd x = mk(r1.x - r2.y, r1.y + r2.x), z = mk(r1.x + r2.y, r2.x - r1.y);
       // lower half: v[u] = own x, v[HR + u] = the upper half's x;  upper half: v[u] = the lower half's z, v[HR + u] = own z
       swap_pair(x.x, z.x, v[u].x, v[HR + u].x);
@@ -166,8 +158,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     dft_sym<R1, false>(v);
     if (bf < NB1) axis_store<R1>(tile, upper, Axes<R1, R2, R3>::base1(bf), Axes<R1, R2, R3>::kStride1, v);   // in place
   } else if (tid == 192) {                                    // bin 0 (the row's last position) bypasses the convolution
-    const cd r1 = whiten_unit(sa[L], sb[L], ha[L], hb[L]);
-    const cd r2 = cscale(whiten_unit(sc[L], sd[L], hc[L], hd[L]), keep2);
+    const cd r1 = whiten(sa[L], sb[L]);
+    const cd r2 = cscale(whiten(sc[L], sd[L]), keep2);
     const cd x = mk(r1.x - r2.y, r1.y + r2.x), z = mk(r1.x + r2.y, r2.x - r1.y);
     dc[0] = x; dc[1] = z;
   }
