@@ -358,6 +358,7 @@ def main() -> None:
     w_b = info["conv_len"] * 16 / 2                               # four-step workspace W per pair
 
     def own(name):
+        if "k_pfa_cols_fin" in name: return y_b                   # the column pass that finishes its rows: Y in, 48-byte records out
         if "k_pfa_cols" in name: return y_b + corr_b              # (also the fused k_pfa_cols_stats)
         if "k_pfa_rows" in name: return spec_b + y_b
         if "k_peak_stream" in name: return corr_b

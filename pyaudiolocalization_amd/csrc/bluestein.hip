@@ -319,8 +319,8 @@ int Engine::alloc_conv(Conv& c, size_t needed) {
   // Register-resident rows (conv_kernels.h k_colsreg_* / k_rowsreg) where the columns then fit one lane comfortably: rows
   // of 4096 points with 12 ... 24-point columns, or rows of 8192 points with 6 ... 24-point columns (measured on C2 / C3 / C5
   // and at n = 88 203 with the prime-factor route off: +13 ... +19 % over the LDS-tile passes either way, the shorter rows
-  // ahead where both fit; 32- and 48-point columns need 250 registers per lane and gain nothing: C4's 393 216 = 48 x 8192
-  // stays on the LDS tiles).  A column length only needs a DFT that fits one lane - 2^a, 3 * 2^a, or 2 x 9 / 10 / 11
+  // ahead where both fit; 32- and 48-point columns need 250 registers in one lane, so they are shared by two neighbouring
+  // lanes (k_colsreg2_*, rows of 8192 points: C4's 393 216 = 48 x 8192, +5 %).  A column length only needs a DFT that fits one lane - 2^a, 3 * 2^a, or 2 x 9 / 10 / 11
   // (reg_fft.h reg_dft) - so the convolution length is the smallest M1 x 2^12 / 2^13 that holds the sequence, in steps
   // of about 10 % instead of the 2^k / 3 * 2^k ladder (88 203 points: 22 x 8192 = 180 224 instead of 196 608).
   // PAL_FOUR_REG = 12 / 13 forces a row length (columns up to 48 points then), 0 turns the route off.
@@ -333,7 +333,7 @@ int Engine::alloc_conv(Conv& c, size_t needed) {
       if ((four_reg == 12 || four_reg == 13) && lr != four_reg) continue;
       for (int m1 : kCols) {
         if (lr == 12 && m1 < 12) continue;
-        if (m1 > 24 && (lr != 13 || four_reg == 0)) continue;      // 32- / 48-point columns: two lanes per column, rows of 8192
+        if (m1 > 24 && lr != 13) continue;                 // 32- / 48-point columns: two lanes per column, rows of 8192
         const size_t m = size_t(m1) << lr;
         if (m < needed || m > c.m) continue;               // (never longer than the 2^k / 3 * 2^k choice)
         if (!best_m || m < best_m) { best_m = m; best_lr = lr; best_m1 = m1; }   // ties: the shorter rows (lr = 12 comes first)

@@ -125,7 +125,7 @@ template <int R, bool INV> PAL_HD void dftR(cd* v) {
 // log2 of the radix of the stage that starts with lp bits done in a length-2^ln transform: 16 when exactly
 // four or at least seven bits remain, 4 when five remain (so that the LAST stage is the radix-8 one: the fused seam of the
 // prime-factor row pass needs a last stage of radix 8 or 16), else 8, then a 4 / 2 tail:
-// 4:[16] 5:[4,8] 6:[8,8] 7:[16,8] 8:[16,16] 9:[16,4,8] 10:[16,8,8] 11:[16,16,8] 12:[16,16,16] 13:[16,16,4,8] 14:[16,16,16,4]
+// 4:[16] 5:[4,8] 6:[8,8] 7:[16,8] 8:[16,16] 9:[16,4,8] 10:[16,8,8] 11:[16,16,8] 12:[16,16,16] 13:[16,16,4,8] 14:[16,16,8,8]
 PAL_HD constexpr int stage_log2r(int ln, int lp) {
   return (ln - lp) == 4 || (ln - lp) >= 7 ? 4 : ((ln - lp) == 5 ? 2 : ((ln - lp) >= 3 ? 3 : (ln - lp)));
 }

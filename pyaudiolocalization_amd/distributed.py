@@ -78,7 +78,7 @@ def sharded_pair_table(frame: np.ndarray, rank: int, world: int, compute_block: 
     pairs = pair_list(m)
     sizes = [shard_pairs(m, r, world)[1] - shard_pairs(m, r, world)[0] for r in range(world)]
     lo, hi = shard_pairs(m, rank, world)
-    if hi <= lo:
+    if min(sizes) <= 0:                                     # decided identically on EVERY rank, before any collective (no rank waits for one that raised)
         raise ValueError("more ranks than pairs")
     local = compute_block(frame, pairs[lo:hi])
     if local.shape != (hi - lo,):
@@ -96,7 +96,7 @@ def sharded_tdoa(frames_of: Callable[[int, int], np.ndarray], total_frames: int,
     """frames_of(first, count) builds this rank's frames, ``compute`` maps frames[B][M][L] to a table[B][P];
     returns the whole job's table[total_frames][P] on every rank."""
     lo, hi = shard_range(total_frames, rank, world)
-    local = compute(frames_of(lo, hi - lo)) if hi > lo else None
-    if local is None:
+    if total_frames < world:                                 # decided identically on every rank, before any collective
         raise ValueError("more ranks than frames")
+    local = compute(frames_of(lo, hi - lo))
     return gather(local, total_frames, rank, world)

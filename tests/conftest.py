@@ -24,11 +24,33 @@ def pytest_sessionstart(session):
     that has initialised HIP ever forks or execs (the GPU boxes forbid an exec from such a process)."""
     import multiprocessing
     import multiprocessing.forkserver as forkserver
+    global FORKSERVER_OK
     try:
         multiprocessing.get_context("forkserver")
         forkserver.ensure_running()
-    except Exception as exc:                     # reported, never fatal: only the two-rank GPU test needs it
+        FORKSERVER_OK = True
+    except Exception as exc:                     # reported, never fatal: only the two-rank GPU tests need it
+        FORKSERVER_OK = False
         print(f"[conftest] fork server not started: {exc}")
+
+
+FORKSERVER_OK = False
+
+
+def require_forkserver():
+    """Skip (never respawn): a test that starts processes through the fork server must not let multiprocessing relaunch
+    it now - that would be a fork + exec from a process that has initialised HIP, which the GPU boxes forbid."""
+    import multiprocessing.forkserver as forkserver
+    alive = False
+    try:
+        pid = getattr(forkserver._forkserver, "_forkserver_pid", None)
+        if pid:
+            os.kill(pid, 0)
+            alive = True
+    except Exception:
+        alive = False
+    if not (FORKSERVER_OK and alive):
+        pytest.skip("the fork server of the test session is not running (it must predate every HIP call)")
 
 
 def load_golden(name):

@@ -63,6 +63,8 @@ def test_bench_line_keeps_the_contract():
     """`python bench.py` (reduced frames / steps) prints ONE JSON line with every contract key, the roofline block and the
     CPU baseline; the pairs it samples select the oracle's indices."""
     import multiprocessing as mp
+    import conftest
+    conftest.require_forkserver()
     ctx = mp.get_context("forkserver")          # started in conftest.pytest_sessionstart, before this process touched the GPU
     queue = ctx.Queue()
     p = ctx.Process(target=_run_bench, args=(["--steps", "2", "--warmup", "1", "--frames", "2", "--cpu-mics", "6"], queue))

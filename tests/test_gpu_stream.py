@@ -224,6 +224,8 @@ def test_two_ranks_engine_compute_gloo_gather(engine, mode):
     GPU), block partition of the frames - or of one frame's pair list - and one gather; every rank ends with the
     single-process table.  (RCCL itself needs one device per rank: its multi-rank gather runs on the driver's 8-GPU node.)"""
     import multiprocessing as mp
+    import conftest
+    conftest.require_forkserver()
     ctx = mp.get_context("forkserver")          # started in conftest.pytest_sessionstart, before this process touched the GPU
     queue = ctx.Queue()
     port = _free_port()
