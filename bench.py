@@ -59,6 +59,16 @@ def fp64_flops_per_pair(info: dict, mics: int, length: int):
     n, n1, n2, tile = info["n"], info.get("n1", 0), info.get("n2", 0), info.get("tile_len", 0)
     pairs = mics * (mics - 1) // 2
     stats = 7.0 * n                                             # streaming statistics: min, two shifted sums of squares
+    if n1 == 89 and tile == n2 - 1 and n2 == 991 and os.environ.get("PAL_R89", "1") != "0":
+        # Rader rows (9 x 10 x 11) and Rader columns (8 x 11 over four wavefronts, csrc/pfa_rader89.h)
+        nr = (n1 + 1) // 2
+        whiten = 66.0 * nr * n2
+        rader = 2 * nr * (2 * (90 * 250 + 110 * 168 + 99 * 92) + 990 * 6)
+        epilogue = 8.0 * n
+        cols = n2 * 4 * (2 * (2 * 250 + 11 * 10) + 3 * 112)       # per column: four wavefronts x (stages A and C, three frequencies of stage B)
+        per_transform = whiten + rader + epilogue + cols
+        forward = per_transform * (mics / 2.0) / pairs
+        return (per_transform / 2.0) + forward + 12.0 * n
     if n1 and tile == n2 - 1 and n2 == 991:                     # prime-factor cut with Rader rows (9 x 10 x 11)
         nr = (n1 + 1) // 2
         whiten = 66.0 * nr * n2                                 # two whitened bins + the packed combinations per position
@@ -444,6 +454,7 @@ def main() -> None:
                                    f"{pairs} pairs/frame, max_expected_delay={med}; {route}",
                        "name": args.config, "frames_per_step_per_gpu": b, "mics": m, "samples": length, "pairs_per_frame": pairs,
                        "fused_column_statistics": os.environ.get("PAL_FUSED", "default"),
+                       "finishing_column_pass": os.environ.get("PAL_FIN", "default"), "rader_columns": os.environ.get("PAL_R89", "default"),
                        "gather": gather, "parallelism": f"frames sharded over {world} GPU(s)"},
             "roofline": roofline, "roofline_fp64": roofline_fp64, "binding_roofline": binding,
             "cpu_baseline": cpu, "parity": parity, "kernels_ms": kernels,
