@@ -372,17 +372,18 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
 
 
 // ---- the column pass that finishes the rows itself (pfa_cols_fin.h): no correlation rows in HBM, no finish launch ----
-// One peak per row (main.py:204), the caller does not ask for `corr`, the column DFT has two to four chunks of output
-// indices (25 <= N1 <= 89) and rows of at least 128 columns.
+// One peak per row (main.py:204), the caller does not ask for `corr`, the fused column pass applies (N1 <= 89) and the grid's
+// rows have at least 256 columns.
 bool Engine::pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const {
   const Pfa& f = pl.pfa;
-  return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.nch >= 2 && f.n2 >= 128;
+  return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.n2 >= 256;
 }
 
 int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, const int* zero_rows,
                                const pal_phat_params& prm, int n2, pal_pair_record* table, int* need, int slot, hipStream_t on) {
   const Pfa& f = pl.pfa;
-  const int nblk = (f.n2 + kColsOwn - 1) / kColsOwn;
+  const bool shortcols = f.nch <= 1;                           // short column DFTs (N1 <= 23): the four wavefronts of a block are four strips
+  const int nblk = (f.n2 + (shortcols ? 4 : 1) * kColsOwn - 1) / ((shortcols ? 4 : 1) * kColsOwn);
   const int n = pl.n;
   PeakArgs a;
   PAL_TRY(peaks_setup(nullptr, 0, rows, n, n2, prm, nblk, f.n2, on, a));
@@ -452,17 +453,19 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
     const dim3 grid(nwg);
     const bool full = (f.n1 - 1) / 2 == f.nch * kPfaTC;
     // histograms only where the bound sqrt(2 mean(x^2)) on the median cannot decide: multipliers above 2 (or negative)
-    const bool adaptive = a.method > 0 || fa.cheb;             // (template flag: no histograms)
+    const bool hist = !(a.method > 0 || fa.cheb);
     const int nw = f.nch == 2 ? 2 : 4;
-#define PAL_COLS_FIN(AD, FU, NW) k_pfa_cols_fin<kPfaTC, kPfaUnr, !(AD), FU, NW><<<grid, dim3(64 * NW), 0, on>>>(Y, f.n1, f.n2, G, f.nch, nblk, f.T, zero_rows, a, fa, rows)
-#define PAL_COLS_FIN_NW(AD, FU) do { if (nw == 2) PAL_COLS_FIN(AD, FU, 2); else PAL_COLS_FIN(AD, FU, 4); } while (0)
-    if (f.r89 && full && nw == 4) {
-      const Rader89Tab* tab = static_cast<const Rader89Tab*>(f.r89);
-      if (adaptive) k_pfa_cols_fin<kPfaTC, kPfaUnr, false, true, 4, true><<<grid, dim3(256), 0, on>>>(Y, f.n1, f.n2, G, f.nch, nblk, f.T, zero_rows, a, fa, rows, tab);
-      else k_pfa_cols_fin<kPfaTC, kPfaUnr, true, true, 4, true><<<grid, dim3(256), 0, on>>>(Y, f.n1, f.n2, G, f.nch, nblk, f.T, zero_rows, a, fa, rows, tab);
-    } else if (adaptive) { if (full) PAL_COLS_FIN_NW(true, true); else PAL_COLS_FIN_NW(true, false); }
-    else { if (full) PAL_COLS_FIN_NW(false, true); else PAL_COLS_FIN_NW(false, false); }
-#undef PAL_COLS_FIN_NW
+    FinSrc src{Y, f.T, static_cast<const Rader89Tab*>(f.r89), nullptr, nullptr, nullptr};
+#define PAL_COLS_FIN(MODE, HI, FU, NW) k_pfa_cols_fin<MODE, kPfaTC, kPfaUnr, HI, FU, NW><<<grid, dim3(64 * NW), 0, on>>>(src, f.n1, f.n2, G, f.nch, nblk, zero_rows, a, fa, rows)
+    if (shortcols) { if (hist) PAL_COLS_FIN(kColsStrips, true, false, 4); else PAL_COLS_FIN(kColsStrips, false, false, 4); }
+    else if (f.r89 && full && nw == 4) { if (hist) PAL_COLS_FIN(kColsRader89, true, true, 4); else PAL_COLS_FIN(kColsRader89, false, true, 4); }
+    else if (nw == 2) {
+      if (hist) { if (full) PAL_COLS_FIN(kColsDense, true, true, 2); else PAL_COLS_FIN(kColsDense, true, false, 2); }
+      else { if (full) PAL_COLS_FIN(kColsDense, false, true, 2); else PAL_COLS_FIN(kColsDense, false, false, 2); }
+    } else {
+      if (hist) { if (full) PAL_COLS_FIN(kColsDense, true, true, 4); else PAL_COLS_FIN(kColsDense, true, false, 4); }
+      else { if (full) PAL_COLS_FIN(kColsDense, false, true, 4); else PAL_COLS_FIN(kColsDense, false, false, 4); }
+    }
 #undef PAL_COLS_FIN
     PAL_HIP(hipGetLastError());
   }

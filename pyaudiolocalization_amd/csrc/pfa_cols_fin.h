@@ -348,16 +348,37 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
   }
 }
 
+// Where the samples of a column block come from
+//   kColsDense     prime-factor grid, dense column DFT: the NW wavefronts are chunks of P1 = TC output indices of ONE 62-column strip
+//   kColsRader89   prime-factor grid, N1 = 89: Rader's 8 x 11 convolution spread over four wavefronts (pfa_rader89.h)
+//   kColsStrips    prime-factor grid, short dense column DFT (one chunk, N1 <= 23): the wavefronts are NW neighbouring strips
+//   kColsFourStep  last pass of the four-step chirp convolution with register rows (conv_kernels.h k_colsreg_inv): a lane holds the
+//                  P1 = M1 points of one column of the 2^P2-column workspace, sample m = r 2^P2 + c, the last row is partial
+//                  (m < n); the wavefronts are NW neighbouring strips
+enum { kColsDense = 0, kColsRader89 = 1, kColsStrips = 2, kColsFourStep = 3 };
+
+struct FinSrc {
+  const cd* Y;                    // prime-factor grid [G][N1][N2], or the four-step workspace [G][M1][2^LR]
+  const double* T;                // dense column DFT: cos / sin table (pfa_kernels.h)
+  const Rader89Tab* tab;          // kColsRader89
+  const cd *twA, *twB, *w;        // kColsFourStep: root tables of the convolution, chirp exp(i pi j^2 / n)
+};
+
 // grid: 8 * ceil(G / 8) * nblk workgroups; index b -> XCD stream b & 7, slot b >> 3; the transforms g = x, x + 8, ... of stream x
 // take nblk consecutive slots each (siblings adjacent, one XCD's L2 behind them when G is a multiple of 8)
-// R89: the column DFT is Rader's 8 x 11 convolution over the four wavefronts (pfa_rader89.h) instead of the dense form
 // HIST: threshold method 'median' with a histogram window per block (a rigorous 0.5 % interval for the row's median); false:
 //       'adaptive', or 'median' bounded without histograms (FinArgs.cheb: multipliers up to 2)
-template <int TC, int UNR, bool HIST, bool FULL, int NW, bool R89 = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) void k_pfa_cols_fin(const cd* __restrict__ Y, int N1, int N2, int G, int nch, int nblk,
-                                                      const double* __restrict__ T, const int* __restrict__ zero_rows, PeakArgs pa,
-                                                      FinArgs fa, int rows, const Rader89Tab* __restrict__ tab = nullptr) {
+template <int MODE, int P1, int P2, bool HIST, bool FULL, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE == kColsFourStep && (P1 > 16) ? 2 : 3))) void k_pfa_cols_fin(FinSrc src, int N1, int N2, int G, int nch, int nblk,
+                                                      const int* __restrict__ zero_rows, PeakArgs pa, FinArgs fa, int rows) {
+  constexpr bool R89 = MODE == kColsRader89, FOUR = MODE == kColsFourStep;
+  constexpr bool STRIPS = MODE == kColsStrips || MODE == kColsFourStep;
+  constexpr int TC = FOUR ? 1 : P1, UNR = FOUR ? 1 : P2;
   static_assert(!R89 || (NW == 4 && FULL), "the Rader column transform is the four-wavefront N1 = 89 case");
+  static_assert(!FOUR || !HIST, "the four-step last pass finishes its rows without histograms only");
+  const cd* __restrict__ Y = src.Y;
+  const double* __restrict__ T = src.T;
+  const Rader89Tab* __restrict__ tab = src.tab;
   // histograms of |x| (+ one dump bin for the lanes that own nothing); with R89 the same memory is first the exchange plane of
   // the column transform (88 x 64 doubles), and in the finishing block its scratch at the end
   constexpr int kHistDoubles = (2 * (kLogBins + 1) * int(sizeof(unsigned)) + 7) / 8;
@@ -371,7 +392,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
   __shared__ int s_flag;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ch = wave;
+  const int ch = STRIPS ? 0 : wave;
   const int xs = int(blockIdx.x & 7u), slot = int(blockIdx.x >> 3);
   const int cb = slot % nblk, g = xs + 8 * (slot / nblk);
   if (g >= G) return;                                          // (uniform: the grid is padded to whole XCD rounds)
@@ -381,14 +402,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
     ++stamp_at;
   };
   stamp();
-  const int c_lo = int((long long)cb * N2 / nblk), c_hi = int((long long)(cb + 1) * N2 / nblk);   // owned columns [c_lo, c_hi)
-  const bool active = ch < nch;
+  // the grid's columns are dealt evenly to the strips (at most kColsOwn = 62 each: two border lanes per wavefront)
+  const int strips = STRIPS ? nblk * NW : nblk, strip = STRIPS ? cb * NW + wave : cb;
+  const int nact = STRIPS ? NW : nch;                          // wavefronts of a block that hold samples
+  const int c_lo = int((long long)strip * N2 / strips), c_hi = int((long long)(strip + 1) * N2 / strips);   // owned columns [c_lo, c_hi)
+  const bool active = STRIPS ? true : ch < nch;
   const int m2 = c_lo - 1 + lane;
   const bool live = m2 >= 0 && m2 < N2 && lane <= c_hi - c_lo + 1;
   const bool own = live && lane >= 1 && lane <= c_hi - c_lo;
   const bool inner = own && m2 >= 1 && m2 <= N2 - 2;
   const int m2c = m2 < 0 ? 0 : (m2 < N2 ? m2 : N2 - 1);
-  const cd* Yg = Y + size_t(g) * N1 * N2 + m2c;
   const int h = (N1 - 1) / 2;
   const int n = pa.n;
   constexpr bool want_median = HIST;
@@ -397,15 +420,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
     unsigned* hz = &hist[0][0];
     for (int q = tid; q < 2 * (kLogBins + 1); q += LANES) hz[q] = 0;
   }
-  constexpr int TCD = R89 ? 1 : TC;                            // (the dense form's accumulators do not exist in the Rader form)
+  constexpr int TCD = (R89 || FOUR) ? 1 : TC;                  // (the dense form's accumulators exist in the dense forms only)
   double cx[TCD], sy[TCD], cy[TCD], sx[TCD];
   double sumx = 0, sumy = 0;
   cd y0 = mk(0, 0);
-  cd ro[R89 ? kR89Slots : 1];                                  // Rader form: c[t] of the output indices tab->tmap[wave][.]
-  cd c0 = mk(0, 0);                                            //             and c[0] (wavefront 0)
+  cd ro[R89 ? kR89Slots : (FOUR ? P1 : 1)];                    // Rader form: c[t] of the output indices tab->tmap[wave][.]; four-step: the column's P1 points
+  cd c0 = mk(0, 0);                                            // Rader form: c[0] (wavefront 0)
   const double kp = zero_rows && zero_rows[2 * g] ? 0.0 : 1.0, kq = zero_rows && 2 * g + 1 < rows && zero_rows[2 * g + 1] ? 0.0 : 1.0;
+  // four-step: does sample (t, this lane's column) exist?  (the last row of the workspace's grid is partial: m = t N2 + m2 < n)
+  auto ok_at = [&](int t) { return !FOUR || t * N2 + m2 < n; };
   if constexpr (R89) {
-    r89_columns(Yg, N2, wave, lane, tab, lds_big, ro, c0);
+    r89_columns(Y + size_t(g) * N1 * N2 + m2c, N2, wave, lane, tab, lds_big, ro, c0);
     if (want_median) {                                         // (the exchange plane is free now: it becomes the histograms)
       unsigned* hz = &hist[0][0];
       for (int q = tid; q < 2 * (kLogBins + 1); q += LANES) hz[q] = 0;
@@ -413,8 +438,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
     c0.x *= kp; c0.y *= kq;
 #pragma unroll
     for (int i = 0; i < kR89Slots; ++i) { ro[i].x *= kp; ro[i].y *= kq; }
+  } else if constexpr (FOUR) {
+    // conv_kernels.h k_colsreg_inv: the column's M1 points, four-step twiddle, inverse M1-point DFT, then the chirp (bluestein.hip CorrStorer)
+    const cd* in = Y + (size_t(g) * P1 << P2) + m2c;
+#pragma unroll
+    for (int k1 = 0; k1 < P1; ++k1) ro[k1] = in[size_t(k1) << P2];
+    colsreg_twiddle<P1, P2, true>(ro, unsigned(m2c), src.twA, src.twB);
+    reg_dft<P1, true>(ro, src.twA);
+#pragma unroll
+    for (int r = 0; r < P1; ++r) {
+      const int j = (r << P2) + m2c;
+      const cd z = j < n ? cmul(ro[r], src.w[j]) : mk(0, 0);
+      ro[r] = mk(z.x * kp, z.y * kq);
+    }
   } else {
-    if (active) pfa_cols_accumulate<TC, UNR>(Yg, N1, N2, nch, ch, T, y0, cx, sy, cy, sx, sumx, sumy);
+    if (active) pfa_cols_accumulate<TC, UNR>(Y + size_t(g) * N1 * N2 + m2c, N1, N2, nch, ch, T, y0, cx, sy, cy, sx, sumx, sumy);
     if (kp == 0.0) { y0.x = sumx = 0.0; }
     if (kq == 0.0) { y0.y = sumy = 0.0; }
 #pragma unroll
@@ -427,7 +465,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
   // only where it is wanted); t and `exists` are wave-uniform.  Dense form: lag order (t = 0 for chunk 0 only, the chunk
   // ascending, the mirrors descending); Rader form: table order
   auto each_sample = [&](int r, auto&& fn) {
-    if constexpr (R89) {
+    if constexpr (FOUR) {
+#pragma unroll
+      for (int i = 0; i < P1; ++i) fn([&]() { return r ? ro[i].y : ro[i].x; }, i, i * N2 < n);
+    } else if constexpr (R89) {
       const auto* tm = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(&tab->tmap[wave][0]));
       fn([&]() { return r ? c0.y : c0.x; }, 0, wave == 0);
 #pragma unroll
@@ -462,11 +503,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
       char* const hrow = reinterpret_cast<char*>(&hist[r][0]);
       each_sample(r, [&](auto&& value, int t, bool exists) {
         if (!exists) return;
-        const double x = value();
-        const bool up = x > vm || (R89 && x == vm && t < tm);  // (Rader form: not in lag order - the smaller index of equal samples)
+        const double xv = value();
+        const bool ok = ok_at(t);                              // (four-step: the last grid row is partial)
+        const double x = ok ? xv : 0.0;
+        const bool up = ok && (x > vm || (R89 && x == vm && t < tm));  // (Rader form: not in lag order - the smaller index of equal samples)
         vm = up ? x : vm;
         tm = up ? t : tm;
-        vn = min_raw(vn, x);
+        vn = ok ? min_raw(vn, x) : vn;
         s1 += x;
         s2 = __builtin_fma(x, x, s2);
         a1 += fabs(x);
@@ -554,7 +597,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
       each_sample(r, [&](auto&& value, int t, bool exists) {
         if (!exists) return;
         const double x = value();
-        if (mine) st_agent(dst + t, x);
+        if (mine && ok_at(t)) st_agent(dst + t, x);
       });
     }
   }
@@ -589,11 +632,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
           if (__ballot(x >= myfloor)) {
             const int m = m2 + N2 * t;
             const double left = from_lower_lane(x), right = from_upper_lane(x);
-            const bool cand = inner && x >= pfloor && (R89 ? (x > hb || (x == hb && m > mb)) : x >= hb);
+            const bool here = inner && (!FOUR || m <= n - 2);    // (four-step: the row ends inside the grid's last row)
+            const bool cand = here && x >= pfloor && (R89 ? (x > hb || (x == hb && m > mb)) : x >= hb);
             const bool pk = cand && left < x && right < x;
             hb = pk ? x : hb;
             mb = pk ? m : mb;
-            plat = inner && x >= pfloor && left == x ? fmax(plat, x) : plat;
+            plat = here && x >= pfloor && left == x ? fmax(plat, x) : plat;
           }
         });
       }
@@ -651,7 +695,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
     const double want = double(fa.epoch);
     bool late = false;
     for (int q = lane; q < pa.splits * 4; q += 64) {           // (entry = block * 4 + wavefront; idle wavefronts never write theirs)
-      if ((q & 3) >= nch) continue;
+      if ((q & 3) >= nact) continue;
       double v = 0, code = 0;
       int spins = 0;
       for (;;) {                                               // (the entry of this launch: its second word carries the launch number)
@@ -682,7 +726,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
       each_sample(r, [&](auto&& value, int t, bool exists) {
         if (!exists || t < tA || t > tB) return;               // (uniform)
         const double x = value();
-        const bool in = own && (t > tA || inA) && (t < tB || inB);
+        const bool in = own && (t > tA || inA) && (t < tB || inB) && ok_at(t);
         const double xm = in ? x : 0.0;
         w1 += xm;
         w2 = __builtin_fma(xm, xm, w2);
@@ -735,7 +779,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
   FinShared& fsh = *reinterpret_cast<FinShared*>(lds_big);
 #pragma nounroll
   for (int r = 0; r < 2; ++r)
-    if (2 * g + r < rows) fin_row<LANES>(pa, fa, 2 * g + r, N1, N2, nch, fsh, tid);
+    if (2 * g + r < rows) fin_row<LANES>(pa, fa, 2 * g + r, N1, N2, nact, fsh, tid);
   stamp();                                                     // 6: both rows finished (last block only)
 }
 

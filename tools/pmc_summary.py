@@ -18,6 +18,7 @@ def bench_name(kernel):
     k = re.sub(r"k_pfa_rows<(\d+), false>", r"k_pfa_rows<\1>", k)
     k = re.sub(r"k_pfa_cols<[\d, ]+>", "k_pfa_cols", k)
     k = re.sub(r"k_pfa_cols_stats<[^>]*>", "k_pfa_cols_stats", k)
+    k = re.sub(r"k_pfa_cols_fin<[^>]*>", "k_pfa_cols_fin", k)
     k = re.sub(r"k_peak_finish<(true|false)>", "k_peak_finish", k)
     k = re.sub(r"k_rows<(\d+), true>", r"k_rows<\1,conv>", k)
     k = re.sub(r"k_rows<(\d+), false>", r"k_rows<\1,fwd>", k)
