@@ -225,24 +225,26 @@ __global__ __launch_bounds__(256) void k_pair_zero(const int4* __restrict__ quad
   zero_rows[2 * g + 1] = q.z >= 0 && (!nonzero[q.z] || !nonzero[q.w]);
 }
 
-// ---- the pairs the finishing column pass flagged (pfa_cols_fin.h), in pair order: list, packed pair table, scatter ----
-// one workgroup walks the flags in tiles of 1024 (a stable compaction: the packing of the flagged pairs, and with it the
-// last bits of their records, does not depend on the order in which the launch groups finished)
+// ---- the pairs the finishing column pass flagged (pfa_cols_fin.h): their TRANSFORMS, in order, with their original packing
+// (a flagged pair is resolved beside the same partner pair as in the first pass, so its record does not depend on which other
+// pairs of the call were flagged - the last bits of cmax / cmin / snr depend on the partner) ----
+// one workgroup walks the transforms in tiles of 1024 (a stable compaction)
 __global__ __launch_bounds__(1024) void k_flag_list(const int* __restrict__ need, int64_t npairs, int* __restrict__ list, int* __restrict__ count) {
   __shared__ int wsum[16];
   __shared__ int base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t ntr = (npairs + 1) / 2;
   if (tid == 0) base = 0;
   __syncthreads();
-  for (int64_t p0 = 0; p0 < npairs; p0 += 1024) {
-    const int64_t p = p0 + tid;
-    const bool f = p < npairs && need[p] != 0;
+  for (int64_t g0 = 0; g0 < ntr; g0 += 1024) {
+    const int64_t g = g0 + tid;
+    const bool f = g < ntr && (need[2 * g] != 0 || (2 * g + 1 < npairs && need[2 * g + 1] != 0));
     const unsigned long long mask = __ballot(f);
     if (lane == 0) wsum[wave] = __popcll(mask);
     __syncthreads();
     int before = base;
     for (int w = 0; w < wave; ++w) before += wsum[w];
-    if (f) list[before + __popcll(mask & ((1ull << lane) - 1ull))] = int(p);
+    if (f) list[before + __popcll(mask & ((1ull << lane) - 1ull))] = int(g);
     __syncthreads();
     if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base += t; }
     __syncthreads();
@@ -252,23 +254,15 @@ __global__ __launch_bounds__(1024) void k_flag_list(const int* __restrict__ need
 
 __global__ __launch_bounds__(256) void k_flag_quads(const int4* __restrict__ quads, const int* __restrict__ list, int count, int4* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= (count + 1) / 2) return;
-  int v[4] = {0, 0, -1, -1};
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    if (2 * i + h >= count) break;
-    const int p = list[2 * i + h];
-    const int4 q = quads[p >> 1];
-    v[2 * h] = p & 1 ? q.z : q.x;
-    v[2 * h + 1] = p & 1 ? q.w : q.y;
-  }
-  out[i] = make_int4(v[0], v[1], v[2], v[3]);
+  if (i < count) out[i] = quads[list[i]];
 }
 
 __global__ __launch_bounds__(256) void k_flag_scatter(const pal_pair_record* __restrict__ src, const int* __restrict__ list, int count,
-                                                      pal_pair_record* __restrict__ table) {
+                                                      const int* __restrict__ need, int64_t npairs, pal_pair_record* __restrict__ table) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < count) table[list[i]] = src[i];
+  if (i >= 2 * count) return;
+  const int64_t p = 2 * int64_t(list[i >> 1]) + (i & 1);
+  if (p < npairs && need[p]) table[p] = src[i];
 }
 
 // ------------------------------------------------------------------ plans
@@ -657,19 +651,20 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     int count = 0;
     PAL_HIP(hipMemcpyAsync(&count, dcount, sizeof count, hipMemcpyDeviceToHost, stream));
     PAL_HIP(hipStreamSynchronize(stream));
-    if (count > 0) {
+    if (count > 0) {                                           // `count` transforms hold a flagged pair
       void *qp = nullptr, *tp = nullptr;
-      PAL_TRY(scratch(20, size_t((count + 1) / 2) * sizeof(int4), &qp));
-      PAL_TRY(scratch(21, size_t(count) * sizeof(pal_pair_record), &tp));
-      k_flag_quads<<<dim3(unsigned(((count + 1) / 2 + 255) / 256)), dim3(256), 0, stream>>>(quads, list, count, static_cast<int4*>(qp));
+      PAL_TRY(scratch(20, size_t(count) * sizeof(int4), &qp));
+      PAL_TRY(scratch(21, size_t(2 * count) * sizeof(pal_pair_record), &tp));
+      k_flag_quads<<<dim3(unsigned((count + 255) / 256)), dim3(256), 0, stream>>>(quads, list, count, static_cast<int4*>(qp));
       PAL_HIP(hipGetLastError());
       const bool keep = fin_cols;
       fin_cols = false;
-      const int rc = pair_correlations(pl, spectra, nspec, static_cast<const int4*>(qp), count, n2, prm, static_cast<pal_pair_record*>(tp), nullptr,
-                                       nullptr, nonzero);
+      const int rc = pair_correlations(pl, spectra, nspec, static_cast<const int4*>(qp), int64_t(2) * count, n2, prm, static_cast<pal_pair_record*>(tp),
+                                       nullptr, nullptr, nonzero);
       fin_cols = keep;
       PAL_TRY(rc);
-      k_flag_scatter<<<dim3(unsigned((count + 255) / 256)), dim3(256), 0, stream>>>(static_cast<const pal_pair_record*>(tp), list, count, table);
+      k_flag_scatter<<<dim3(unsigned((2 * count + 255) / 256)), dim3(256), 0, stream>>>(static_cast<const pal_pair_record*>(tp), list, count, need,
+                                                                                      npairs, table);
       PAL_HIP(hipGetLastError());
     }
   }

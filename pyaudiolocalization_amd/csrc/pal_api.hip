@@ -112,8 +112,12 @@ static int check_status(Engine* e) {
     }
     int flagged = 0;
     if (hipMemcpy(&flagged, static_cast<int*>(e->ws[7]) + 4, sizeof flagged, hipMemcpyDeviceToHost) == hipSuccess && flagged) {
-      fprintf(stderr, "[pal] %d row(s) of the finishing column pass went through the stored-row launches\n", flagged);
-      hipMemset(static_cast<int*>(e->ws[7]) + 4, 0, sizeof flagged);
+      int why[8] = {};
+      (void)hipMemcpy(why, static_cast<int*>(e->ws[7]) + 5, sizeof why, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[pal] %d row(s) of the finishing column pass went through the stored-row path (no maximum %d, tie %d, tie in window %d, "
+                      "SNR window energy %d, histogram windows %d, threshold interval %d, window interval %d, window edge %d)\n",
+              flagged, why[0], why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
+      hipMemset(static_cast<int*>(e->ws[7]) + 4, 0, sizeof flagged + sizeof why);
     }
   }
   int in = 0;                                // word 2: input problems found by device-side checks

@@ -372,11 +372,14 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
 
 
 // ---- the column pass that finishes the rows itself (pfa_cols_fin.h): no correlation rows in HBM, no finish launch ----
-// One peak per row (main.py:204), the caller does not ask for `corr`, the fused column pass applies (N1 <= 89) and the grid's
-// rows have at least 256 columns.
+// One peak per row (main.py:204), the caller does not ask for `corr`, the column DFT has two to four chunks of output indices
+// (25 <= N1 <= 89) and the grid's rows have at least 256 columns.  Short column DFTs (one chunk, N1 <= 23: four strips per
+// block) keep the stored-row pass unless PAL_FIN_STRIPS=1: a lane then holds only N1 samples per row, and the exchange between
+// the blocks and the serial finish cost more than the stores and the finish launch they replace (C3: 0.95 against 1.11 M pairs/s).
 bool Engine::pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const {
   const Pfa& f = pl.pfa;
-  return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.n2 >= 256;
+  static const bool strips = getenv("PAL_FIN_STRIPS") != nullptr;
+  return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.n2 >= 256 && (f.nch >= 2 || strips);
 }
 
 int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, const int* zero_rows,

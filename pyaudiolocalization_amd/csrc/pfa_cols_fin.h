@@ -44,11 +44,12 @@ namespace pal {
 struct FinPartial {               // what one column block hands to the finishing block, per row (whole 8-byte words)
   double vmin, hb, plat;          // minimum; highest strict peak (mb = -1: none); highest sample with an equal neighbour (-inf: none)
   double s1, s2, a1;              // sum x, sum x^2, sum |x|
-  double hw, platw;               // lag window: highest strict peak inside it (mw = -1: none), highest tie inside it
+  double hw, platw;               // lag window: highest strict peak inside it (mw = -1: none), highest tie inside it or its margins
+  double hm;                      // highest strict peak in the margins of distance - 1 samples beside the window (mm = -1: none)
   double w1, w2;                  // sum x, sum x^2 of the block's samples inside the SNR window around the row's maximum
-  int mb, mw;
+  int mb, mw, mm, pad;
 };
-static_assert(sizeof(FinPartial) == 88, "eleven words");
+static_assert(sizeof(FinPartial) == 104, "thirteen words");
 
 struct FinArgs {
   pal_pair_record* table;         // [rows] records of this launch group
@@ -66,8 +67,8 @@ struct FinArgs {
 };
 
 struct FinWave {                  // one wavefront's share of the finishing block's merge
-  double vmax, hb, hw, plat, platw, nvmin, s1, s2, a1, w1, w2;
-  int imax, mb, mw, pad;
+  double vmax, hb, hw, hm, plat, platw, nvmin, s1, s2, a1, w1, w2;
+  int imax, mb, mw, mm;
 };
 
 struct FinShared {                // finishing block's scratch, laid over the histograms of phase 1
@@ -113,7 +114,9 @@ __device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)
 typedef double pal_d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st_agent16(double* p, double a, double b) {                 // one aligned 16-byte store, device scope
   const pal_d2 v = {a, b};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  // (s_nop: a store of more than 8 bytes reads its upper data registers a cycle late - the compiler knows that hazard for
+  //  its own stores, not for inline assembly, and the registers are dead for it behind this statement)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void ld_agent16(const double* p, double& a, double& b) {
   pal_d2 v;
@@ -136,8 +139,8 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
   // ---- every lane: some wavefronts' maxima, at most a few blocks' results and edge samples; merged locally, then across the workgroup
   double vmax = 0, vmin = INFINITY, hb = 0, plat = -INFINITY, s1 = 0, s2 = 0, a1 = 0, w1 = 0, w2 = 0;
   int imax = -1, mb = -1;
-  double hw = 0, platw = -INFINITY;
-  int mw = -1;
+  double hw = 0, hm = 0, platw = -INFINITY;
+  int mw = -1, mm = -1;
   {
     const double* em = fa.emax + size_t(row) * S * 8;
     for (int q = tid; q < S * 4; q += LANES) {
@@ -156,6 +159,7 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
     w1 += pt.w1; w2 += pt.w2;
     if (windowed) {
       if (pt.mw >= 0 && (mw < 0 || higher(pt.hw, pt.mw, hw, mw))) { hw = pt.hw; mw = pt.mw; }
+      if (pt.mm >= 0 && (mm < 0 || higher(pt.hm, pt.mm, hm, mm))) { hm = pt.hm; mm = pt.mm; }
       platw = fmax(platw, pt.platw);
     }
   }
@@ -172,10 +176,12 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
     const bool tie = xl == x || xr == x;
     const bool pk = xl < x && xr < x;
     const bool inw = windowed && m >= fa.win_lo && m <= fa.win_hi;
+    const bool inm = windowed && !inw && m >= fa.win_lo - (pa.dist - 1) && m <= fa.win_hi + (pa.dist - 1);
     if (tie) plat = fmax(plat, x);
-    if (tie && inw) platw = fmax(platw, x);
+    if (tie && (inw || inm)) platw = fmax(platw, x);
     if (pk && (mb < 0 || higher(x, m, hb, mb))) { hb = x; mb = m; }
     if (pk && inw && (mw < 0 || higher(x, m, hw, mw))) { hw = x; mw = m; }
+    if (pk && inm && (mm < 0 || higher(x, m, hm, mm))) { hm = x; mm = m; }
   }
   {
     double nvmin = -vmin;
@@ -189,6 +195,9 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
       const double wv = shfl_down_d(hw, o);
       const int wi = __shfl_down(mw, o, 64);
       if (wi >= 0 && (mw < 0 || higher(wv, wi, hw, mw))) { hw = wv; mw = wi; }
+      const double gv = shfl_down_d(hm, o);
+      const int gi = __shfl_down(mm, o, 64);
+      if (gi >= 0 && (mm < 0 || higher(gv, gi, hm, mm))) { hm = gv; mm = gi; }
       plat = fmax(plat, shfl_down_d(plat, o));
       platw = fmax(platw, shfl_down_d(platw, o));
       nvmin = fmax(nvmin, shfl_down_d(nvmin, o));
@@ -198,35 +207,37 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
     __syncthreads();                                           // (the previous row's readers are done with the scratch)
     if ((tid & 63) == 0) {
       FinWave& w = fs.wave[tid >> 6];
-      w.vmax = vmax; w.imax = imax; w.hb = hb; w.mb = mb; w.hw = hw; w.mw = mw; w.plat = plat; w.platw = platw; w.nvmin = nvmin;
+      w.vmax = vmax; w.imax = imax; w.hb = hb; w.mb = mb; w.hw = hw; w.mw = mw; w.hm = hm; w.mm = mm; w.plat = plat; w.platw = platw; w.nvmin = nvmin;
       w.s1 = s1; w.s2 = s2; w.a1 = a1; w.w1 = w1; w.w2 = w2;
     }
     __syncthreads();
     const FinWave w0 = fs.wave[0];
-    vmax = w0.vmax; imax = w0.imax; hb = w0.hb; mb = w0.mb; hw = w0.hw; mw = w0.mw; plat = w0.plat; platw = w0.platw; nvmin = w0.nvmin;
+    vmax = w0.vmax; imax = w0.imax; hb = w0.hb; mb = w0.mb; hw = w0.hw; mw = w0.mw; hm = w0.hm; mm = w0.mm; plat = w0.plat; platw = w0.platw; nvmin = w0.nvmin;
     s1 = w0.s1; s2 = w0.s2; a1 = w0.a1; w1 = w0.w1; w2 = w0.w2;
     for (int k = 1; k < NW; ++k) {
       const FinWave w = fs.wave[k];
       if (w.imax >= 0 && (imax < 0 || arg_better<0>(w.vmax, w.imax, vmax, imax))) { vmax = w.vmax; imax = w.imax; }
       if (w.mb >= 0 && (mb < 0 || higher(w.hb, w.mb, hb, mb))) { hb = w.hb; mb = w.mb; }
       if (w.mw >= 0 && (mw < 0 || higher(w.hw, w.mw, hw, mw))) { hw = w.hw; mw = w.mw; }
+      if (w.mm >= 0 && (mm < 0 || higher(w.hm, w.mm, hm, mm))) { hm = w.hm; mm = w.mm; }
       plat = fmax(plat, w.plat); platw = fmax(platw, w.platw); nvmin = fmax(nvmin, w.nvmin);
       s1 += w.s1; s2 += w.s2; a1 += w.a1; w1 += w.w1; w2 += w.w2;
     }
     vmin = -nvmin;
   }
   bool flag = false;                                           // the row needs its samples: stored-row path at the end of the call
-  if (imax < 0 || imax >= n) { imax = 0; flag = true; }
+  int why = 0;                                                 // (diagnostics: which rule flagged it)
+  if (imax < 0 || imax >= n) { imax = 0; flag = true; why |= 1; }
   // a tie that may outrank the best strict peak (plateaus are resolved from the stored row)
-  if (plat > -INFINITY && (mb < 0 || plat >= hb)) flag = true;
-  if (windowed && platw > -INFINITY && (mw < 0 || platw >= hw)) flag = true;
+  if (plat > -INFINITY && (mb < 0 || plat >= hb)) { flag = true; why |= 2; }
+  if (windowed && platw > -INFINITY && (mw < 0 || platw >= hw)) { flag = true; why |= 4; }
 
   // ---- SNR (utils.py:238-250): totals minus the window around the maximum
   const int wlo_s = imax - pa.snr_w > 0 ? imax - pa.snr_w : 0;
   const int whi_s = imax + pa.snr_w < n ? imax + pa.snr_w : n;
   const double nn = double(n - (whi_s - wlo_s));
   const double o1 = s1 - w1, o2 = s2 - w2;
-  if (!(o2 >= 0.25 * s2)) flag = true;                         // the window holds most of the energy: two-pass sum of the noise region
+  if (!(o2 >= 0.25 * s2)) { flag = true; why |= 8; }           // the window holds most of the energy: two-pass sum of the noise region
   double var = (o2 - o1 * o1 / nn) / nn;
   if (var < 0) var = 0;
   const double noise = sqrt(var);
@@ -295,6 +306,7 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
       thi = pa.mult >= 0 ? pa.mult * mh_ : pa.mult * ml_;
     } else {
       flag = true;                                             // the windows missed the row's median: exact select over the stored row
+      why |= 16;
     }
   }
 
@@ -308,6 +320,7 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
     if (mb >= 0 && hb >= thi) {
     } else if (mb >= 0 && hb >= tlo) {
       flag = true;                                             // inside the median's interval
+      why |= 32;
     } else {
       branch |= PAL_BR_ALT_THRESHOLD;
       alt = true;
@@ -320,7 +333,7 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
         const double t_lo = alt ? mean_abs : tlo, t_hi = alt ? mean_abs : thi;
         bool found = false;
         if (mw >= 0 && hw >= t_hi) found = true;
-        else if (mw >= 0 && hw >= t_lo) flag = true;
+        else if (mw >= 0 && hw >= t_lo) { flag = true; why |= 64; }
         if (!flag && !found) {                                 // no peak of the first search inside the window: mean(|corr|), then argmax
           branch |= PAL_BR_WINDOW_RETRY;
           if (mw >= 0 && hw >= mean_abs) found = true;
@@ -328,8 +341,11 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
         }
         if (found) {
           // the window's best peak is kept unless a HIGHER peak lies closer than `distance`; inside the window there is none,
-          // and a sample outside it is that close only to peaks within distance - 2 of the window's edge
-          if (mw - fa.win_lo < pa.dist - 1 || fa.win_hi - mw < pa.dist - 1) flag = true;
+          // and a sample outside it is that close only to peaks within distance - 2 of the window's edge.  The margins' best
+          // peak stands for every peak there: only if IT is higher can the window's peak be suppressed (whether it is - the
+          // margin peak may be suppressed itself - is a chain the stored row resolves)
+          const bool near = mw - fa.win_lo < pa.dist - 1 || fa.win_hi - mw < pa.dist - 1;
+          if (near && mm >= 0 && higher(hm, mm, hw, mw)) { flag = true; why |= 128; }
           else { sel = mw; sel_h = hw; }
         }
       }
@@ -338,8 +354,11 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
   }
   if (tid == 0) {
     fa.need[row] = flag ? 1 : 0;
-    if (flag) atomicAdd(fa.status + 4, 1);
-    else {
+    if (flag) {
+      atomicAdd(fa.status + 4, 1);
+      for (int b = 0; b < 8; ++b)
+        if (why >> b & 1) atomicAdd(fa.status + 5 + b, 1);
+    } else {
       pal_pair_record r;
       r.k_sel = sel; r.branch = branch; r.k_argmax = imax; r.n_sel = 1;
       r.cmax = vmax; r.cmin = vmin; r.snr = snr; r.sel_height = sel_h;
@@ -647,12 +666,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
         FinPartial& w = res[wave][r];
         w.hb = hb; w.plat = plat; w.mb = mb;
       }
-      // the lag window: its highest strict peak, whatever its height (a handful of output indices meet the window)
+      // the lag window and its margins of distance - 1 samples: their highest strict peaks, whatever their height (a handful of
+      // output indices meet them)
       if (windowed && round == 0) {
-        const int lo1 = fa.win_lo > 1 ? fa.win_lo : 1, hi1 = fa.win_hi < n - 2 ? fa.win_hi : n - 2;   // (the row's end points are never peaks)
+        const int elo = fa.win_lo - (pa.dist - 1), ehi = fa.win_hi + (pa.dist - 1);
+        const int lo1 = elo > 1 ? elo : 1, hi1 = ehi < n - 2 ? ehi : n - 2;     // (the row's end points are never peaks)
         const int t_lo = lo1 / N2, t_hi = hi1 / N2;
-        double hq = -INFINITY, platw = -INFINITY;
-        int mq = -1;
+        double hq = -INFINITY, hg = -INFINITY, platw = -INFINITY;
+        int mq = -1, mg = -1;
         if (active && lo1 <= hi1) {
           each_sample(r, [&](auto&& value, int t, bool exists) {
             if (!exists || t < t_lo || t > t_hi) return;       // (uniform)
@@ -661,14 +682,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
             const double left = from_lower_lane(x), right = from_upper_lane(x);
             const bool in = inner && m >= lo1 && m <= hi1;
             platw = in && (left == x || right == x) ? fmax(platw, x) : platw;
-            if (in && left < x && right < x && (R89 ? (x > hq || (x == hq && m > mq)) : x >= hq)) { hq = x; mq = m; }
+            const bool pk = in && left < x && right < x;
+            const bool inw = m >= fa.win_lo && m <= fa.win_hi;
+            if (pk && inw && (R89 ? (x > hq || (x == hq && m > mq)) : x >= hq)) { hq = x; mq = m; }
+            if (pk && !inw && (R89 ? (x > hg || (x == hg && m > mg)) : x >= hg)) { hg = x; mg = m; }
           });
         }
         wave_arg63(hq, mq, [](double v1, int i1, double v2, int i2) { return higher(v1, i1, v2, i2); });
+        wave_arg63(hg, mg, [](double v1, int i1, double v2, int i2) { return higher(v1, i1, v2, i2); });
         platw = wave_max63(platw);
         if (lane == 63) {
           FinPartial& w = res[wave][r];
-          w.hw = hq; w.mw = mq; w.platw = platw;
+          w.hw = hq; w.mw = mq; w.hm = hg; w.mm = mg; w.platw = platw;
         }
       }
     }
@@ -743,8 +768,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
     FinPartial pt;
     pt.hb = pt.plat = pt.platw = -INFINITY;
     pt.vmin = INFINITY;
-    pt.mb = pt.mw = -1;
-    pt.s1 = pt.s2 = pt.a1 = pt.hw = pt.w1 = pt.w2 = 0;
+    pt.mb = pt.mw = pt.mm = -1;
+    pt.pad = 0;
+    pt.s1 = pt.s2 = pt.a1 = pt.hw = pt.hm = pt.w1 = pt.w2 = 0;
     for (int w = 0; w < NW; ++w) {
       const FinPartial x = res[w][r];
       pt.vmin = fmin(pt.vmin, x.vmin);
@@ -753,6 +779,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
       pt.plat = fmax(pt.plat, x.plat);
       if (windowed) {
         if (x.mw >= 0 && (pt.mw < 0 || higher(x.hw, x.mw, pt.hw, pt.mw))) { pt.hw = x.hw; pt.mw = x.mw; }
+        if (x.mm >= 0 && (pt.mm < 0 || higher(x.hm, x.mm, pt.hm, pt.mm))) { pt.hm = x.hm; pt.mm = x.mm; }
         pt.platw = fmax(pt.platw, x.platw);
       }
     }

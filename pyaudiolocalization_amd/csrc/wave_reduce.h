@@ -30,7 +30,21 @@ __device__ __forceinline__ double wave_max63(double v) { return wave_reduce_d(v,
 __device__ __forceinline__ double wave_min63(double v) { return wave_reduce_d(v, __builtin_huge_val(), [](double a, double b) { return fmin(a, b); }); }
 
 // (value, index) pairs, index < 0 = no entry.  BETTER(v1, i1, v2, i2): entry 1 beats entry 2 (both present)
+#ifdef PAL_ARG_SHFL
 template <class BETTER> __device__ __forceinline__ void wave_arg63(double& v, int& i, BETTER better) {
+  const int lane = threadIdx.x & 63;
+  for (int o = 1; o < 64; o <<= 1) {
+    const double ov = __shfl_up(v, o, 64);
+    const int oi = __shfl_up(i, o, 64);
+    const bool take = lane >= o && oi >= 0 && (i < 0 || better(ov, oi, v, i));
+    v = take ? ov : v;
+    i = take ? oi : i;
+  }
+}
+template <class BETTER> __device__ __forceinline__ void wave_arg63_dpp(double& v, int& i, BETTER better) {
+#else
+template <class BETTER> __device__ __forceinline__ void wave_arg63(double& v, int& i, BETTER better) {
+#endif
   auto step = [&](double ov, int oi) {
     const bool take = oi >= 0 && (i < 0 || better(ov, oi, v, i));
     v = take ? ov : v;
