@@ -553,7 +553,8 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     PAL_HIP(hipGetLastError());
   }
   // the finishing column pass (pfa_cols_fin.h) writes one flag per pair: 1 = resolved at the end of this call from stored rows
-  const bool fin = pfa && table && !split && pfa_sub == 0 && !corr_out && !ksel_multi && pfa_can_fuse(pl) && pfa_can_finish(pl, prm);
+  const bool fin = table && !split && !corr_out && !ksel_multi &&
+                   (pfa ? pfa_sub == 0 && pfa_can_fuse(pl) && pfa_can_finish(pl, prm) : fourstep_can_finish(pl, prm));
   int* need = nullptr;
   if (fin) {
     void* np = nullptr;
@@ -579,7 +580,7 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     double* crow = via_scratch ? cbuf + size_t(slot) * buf_doubles : corr_out + size_t(p0) * stride;
     if (split && group >= 2) PAL_HIP(hipStreamWaitEvent(stream, ev_peaks[slot], 0));   // group - 2 is done with this buffer
     const bool fused = pfa && table && !split && pfa_sub == 0 && pfa_can_fuse(pl);
-    if (fin) {
+    if (fin && pfa) {
       // nobody reads the correlation rows: the column pass finishes them without storing them (pfa_cols_fin.h)
       PAL_TRY(pfa_pair_group_fin(pl, permuted, quads + t0, G, rows, Wg, zero_rows ? zero_rows + p0 : nullptr, prm, n2, table + p0, need + p0,
                                  slot, on));
@@ -597,10 +598,15 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
       }
     } else {
       PairLoader ld{spectra, quads + t0, n, pl.H, pl.w};
-      CorrStorer st{crow, stride, n, pl.w, zero_rows ? zero_rows + p0 : nullptr};
       PAL_TRY(launch_cols_fwd(e, c, G, ld, Wg, on));
       PAL_TRY(launch_rows(e, c, G, Wg, true, 1.0, on));
-      PAL_TRY(launch_cols_inv(e, c, G, Wg, st, on));
+      if (fin) {
+        // the last pass finishes its rows itself: no correlation rows in HBM, no statistics launches (pfa_cols_fin.h)
+        PAL_TRY(fourstep_pair_group_fin(pl, Wg, G, rows, zero_rows ? zero_rows + p0 : nullptr, prm, n2, table + p0, need + p0, slot, on));
+      } else {
+        CorrStorer st{crow, stride, n, pl.w, zero_rows ? zero_rows + p0 : nullptr};
+        PAL_TRY(launch_cols_inv(e, c, G, Wg, st, on));
+      }
     }
     if (corr_out && via_scratch)
       PAL_HIP(hipMemcpyAsync(corr_out + size_t(p0) * stride, crow, size_t(rows) * stride * sizeof(double),
@@ -611,7 +617,7 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
       PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[slot], 0));
       pon = stream2;
     }
-    if (table && !fused)
+    if (table && !fused && !fin)
       PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr, pon));
     if (split) PAL_HIP(hipEventRecord(ev_peaks[slot], stream2));
     return PAL_OK;

@@ -18,6 +18,7 @@ namespace pal {
 // One circular convolution of length M = M1 x M2 (four-step, both factors in LDS).
 // M2 = 2^l2; M1 = 2^l1, or 3 * 2^l1 (r3) when the 3 * 2^k length is the smaller fit.
 struct PeakArgs;    // peak_types.h
+struct FinArgs;     // pfa_cols_fin.h
 
 struct Conv {
   int l1 = 0, l2 = 0;
@@ -84,6 +85,11 @@ struct Engine {
   hipStream_t stream2 = nullptr;   // second launch-group slot (or the peak selection in PAL_OVERLAP=2)
   hipStream_t stream3 = nullptr;   // third launch-group slot (PAL_OVERLAP=3)
   hipEvent_t ev_join3 = nullptr;
+  hipEvent_t ev_fin = nullptr;     // end of the latest finishing column pass (pfa_cols_fin.h): they run one at a time, see fin_serialize
+  int fin_serialize(hipStream_t on);   // before such a launch: wait for the previous one; fin_done(on) behind it
+  int fin_done(hipStream_t on);
+  bool fin_pending = false;
+  bool fin_serial = false;         // PAL_FIN_SERIAL=1
   hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams
   int overlap = 3;                 // PAL_OVERLAP: 0 one stream; 1 launch groups alternate between two streams; 2 transforms on
                                    // `stream`, peak selection on `stream2`; 3 (default) groups rotate over three streams
@@ -171,6 +177,11 @@ struct Engine {
   int peaks_finish(PeakArgs& a, int rows, pal_pair_record* table, int32_t* ksel_multi, hipStream_t on);
   int pfa_rows(const Plan& pl, const cd* permuted, const int4* quads, int G, cd* Y, hipStream_t on);
   bool pfa_can_fuse(const Plan& pl) const;
+  int fin_setup(const Plan& pl, int rows, int nblk, int grid_rows, int grid_cols, const pal_phat_params& prm, int n2, pal_pair_record* table,
+                int* need, int slot, hipStream_t on, PeakArgs& a, struct FinArgs& fa, unsigned& nwg, int G);
+  bool fourstep_can_finish(const Plan& pl, const pal_phat_params& prm) const;   // pfa_cols_fin.h applies to the four-step last pass
+  int fourstep_pair_group_fin(const Plan& pl, const cd* W, int G, int rows, const int* zero_rows, const pal_phat_params& prm, int n2,
+                              pal_pair_record* table, int* need, int slot, hipStream_t on);
   bool pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const;   // pfa_cols_fin.h applies (one peak per row, N1 of 2..4 chunks)
   int pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, const int* zero_rows,
                          const pal_phat_params& prm, int n2, pal_pair_record* table, int* need, int slot, hipStream_t on);

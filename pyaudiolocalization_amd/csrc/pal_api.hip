@@ -114,10 +114,13 @@ static int check_status(Engine* e) {
     if (hipMemcpy(&flagged, static_cast<int*>(e->ws[7]) + 4, sizeof flagged, hipMemcpyDeviceToHost) == hipSuccess && flagged) {
       int why[8] = {};
       (void)hipMemcpy(why, static_cast<int*>(e->ws[7]) + 5, sizeof why, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[pal] %d row(s) of the finishing column pass went through the stored-row path (no maximum %d, tie %d, tie in window %d, "
-                      "SNR window energy %d, histogram windows %d, threshold interval %d, window interval %d, window edge %d)\n",
-              flagged, why[0], why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
+      int gaveup = 0;
+      (void)hipMemcpy(&gaveup, static_cast<int*>(e->ws[7]) + 13, sizeof gaveup, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[pal] %d row(s) of the finishing column pass went through the stored-row path (no maximum / abandoned %d, tie %d, tie in window %d, "
+                      "SNR window energy %d, histogram windows %d, threshold interval %d, window interval %d, window edge %d; waits given up %d)\n",
+              flagged, why[0], why[1], why[2], why[3], why[4], why[5], why[6], why[7], gaveup);
       hipMemset(static_cast<int*>(e->ws[7]) + 4, 0, sizeof flagged + sizeof why);
+      hipMemset(static_cast<int*>(e->ws[7]) + 13, 0, sizeof gaveup);
     }
   }
   int in = 0;                                // word 2: input problems found by device-side checks
@@ -131,9 +134,6 @@ static int check_status(Engine* e) {
   }
   if (st) {
     hipMemset(e->ws[7], 0, sizeof st);
-    if (st & 4) {
-      return e->fail(PAL_ERR_INTERNAL, "column pass: a workgroup gave up waiting for the other column blocks of its transform (the table of this call is not valid)");
-    }
     return e->fail(PAL_ERR_INTERNAL, "peak selection: suppression chain exceeded the on-chip memo/stack (rows fell back to argmax)");
   }
   return PAL_OK;
@@ -237,6 +237,7 @@ int pal_create(int device, pal_handle* out) {
       (rc = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking)) != hipSuccess ||
       (rc = hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking)) != hipSuccess ||
       (rc = hipEventCreateWithFlags(&e->ev_join3, hipEventDisableTiming)) != hipSuccess ||
+      (rc = hipEventCreateWithFlags(&e->ev_fin, hipEventDisableTiming)) != hipSuccess ||
       (rc = hipEventCreateWithFlags(&e->ev_corr[0], hipEventDisableTiming)) != hipSuccess ||
       (rc = hipEventCreateWithFlags(&e->ev_corr[1], hipEventDisableTiming)) != hipSuccess ||
       (rc = hipEventCreateWithFlags(&e->ev_peaks[0], hipEventDisableTiming)) != hipSuccess ||
@@ -271,6 +272,8 @@ int pal_create(int device, pal_handle* out) {
   if (env) e->fuse_peaks = atoi(env) != 0;
   env = getenv("PAL_R89");
   if (env) e->allow_r89 = atoi(env) != 0;
+  env = getenv("PAL_FIN_SERIAL");
+  if (env) e->fin_serial = atoi(env) != 0;
   env = getenv("PAL_FIN");
   if (env) e->fin_cols = atoi(env) != 0;
   env = getenv("PAL_PFA_SUB");
@@ -296,6 +299,7 @@ void pal_destroy(pal_handle h) {
   hipStreamDestroy(e->stream2);
   hipStreamDestroy(e->stream3);
   hipEventDestroy(e->ev_join3);
+  hipEventDestroy(e->ev_fin);
   hipStreamDestroy(e->stream);
   delete e;
 }

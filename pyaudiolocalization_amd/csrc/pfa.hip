@@ -382,20 +382,34 @@ bool Engine::pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const {
   return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.n2 >= 256 && (f.nch >= 2 || strips);
 }
 
-int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, const int* zero_rows,
-                               const pal_phat_params& prm, int n2, pal_pair_record* table, int* need, int slot, hipStream_t on) {
-  const Pfa& f = pl.pfa;
-  const bool shortcols = f.nch <= 1;                           // short column DFTs (N1 <= 23): the four wavefronts of a block are four strips
-  const int nblk = (f.n2 + (shortcols ? 4 : 1) * kColsOwn - 1) / ((shortcols ? 4 : 1) * kColsOwn);
+// The blocks of a finishing pass wait for their siblings (pfa_cols_fin.h).  ONE such launch is deadlock-free (its workgroups are
+// dispatched in order and siblings are adjacent), but two of them on different streams can fill every workgroup slot of the
+// device with blocks that wait for siblings which then find no slot (seen with the four-step source: 34 blocks per transform,
+// two per CU, three streams).  The kernel's waits are bounded and a block that gives up only sends its rows through the
+// stored-row path, so this costs time, never correctness.  PAL_FIN_SERIAL=1 runs the finishing launches one at a time
+// instead (each waits for the previous one's end, wherever that ran): no such stall can happen, 10 % slower on the metric run.
+int Engine::fin_serialize(hipStream_t on) {
+  if (fin_serial && fin_pending) PAL_HIP(hipStreamWaitEvent(on, ev_fin, 0));
+  return PAL_OK;
+}
+int Engine::fin_done(hipStream_t on) {
+  if (!fin_serial) return PAL_OK;
+  PAL_HIP(hipEventRecord(ev_fin, on));
+  fin_pending = true;
+  return PAL_OK;
+}
+
+// arguments and scratch of one launch of the finishing pass: a grid of `grid_rows` x `grid_cols` samples per row, nblk blocks per transform
+int Engine::fin_setup(const Plan& pl, int rows, int nblk, int grid_rows, int grid_cols, const pal_phat_params& prm, int n2, pal_pair_record* table,
+                      int* need, int slot, hipStream_t on, PeakArgs& a, FinArgs& fa, unsigned& nwg, int G) {
   const int n = pl.n;
-  PeakArgs a;
-  PAL_TRY(peaks_setup(nullptr, 0, rows, n, n2, prm, nblk, f.n2, on, a));
+  PAL_TRY(peaks_setup(nullptr, 0, rows, n, n2, prm, nblk, grid_cols, on, a));
   // per-stream scratch of the finishing pass: [done words G x blocks | emax | parts | edge]
   const int Gmax = pair_group(n);
   const size_t off_emax = (size_t(Gmax) * nblk * sizeof(unsigned) + 127) & ~size_t(127);
   const size_t off_parts = (off_emax + size_t(2 * Gmax) * nblk * 8 * sizeof(double) + 127) & ~size_t(127);
   const size_t off_edge = (off_parts + size_t(2 * Gmax) * nblk * sizeof(FinPartial) + 127) & ~size_t(127);
-  const size_t total = off_edge + size_t(2 * Gmax) * 4 * f.n1 * sizeof(double);
+  const size_t total = off_edge + size_t(2 * Gmax) * 4 * grid_rows * sizeof(double);
   void* sp = nullptr;
   PAL_TRY(scratch(16 + slot, total, &sp));
   char* base = static_cast<char*>(sp);
@@ -405,13 +419,12 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
     PAL_TRY(scratch(7, 64, &stp));
     status = static_cast<int*>(stp);
   }
-  FinArgs fa;
   fa.table = table;
   fa.need = need;
   fa.done = reinterpret_cast<unsigned*>(base);
   // launch number of this stream's scratch: entries of earlier launches fail the comparison (no resets, no counters)
   if (ws_bytes[16 + slot] != fin_bytes[slot] || fin_epoch[slot] >= (1u << 20)) {     // new (zeroed) scratch, or the number would outgrow a double's integers
-    if (fin_epoch[slot] >= (1u << 20)) PAL_HIP(hipMemsetAsync(sp, 0, total, on));
+    PAL_HIP(hipMemsetAsync(sp, 0, total, on));
     fin_bytes[slot] = ws_bytes[16 + slot];
     fin_epoch[slot] = 0;
   }
@@ -443,13 +456,58 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
   fa.cheb = a.method == 0 && prm.threshold_multiplier >= 0 && prm.threshold_multiplier <= 2.0 && !no_cheb ? 1 : 0;
   fa.stamps = nullptr;
   static const bool want_stamps = getenv("PAL_DEBUG_STAMPS") != nullptr;
-  const unsigned nwg = 8u * unsigned((G + 7) / 8) * unsigned(nblk);
+  nwg = 8u * unsigned((G + 7) / 8) * unsigned(nblk);
   if (want_stamps) {
     void* st = nullptr;
     PAL_TRY(scratch(13, size_t(nwg) * 8 * sizeof(unsigned long long), &st));
     PAL_HIP(hipMemsetAsync(st, 0, size_t(nwg) * 8 * sizeof(unsigned long long), on));
     fa.stamps = static_cast<unsigned long long*>(st);
   }
+  return PAL_OK;
+}
+
+// the last pass of the four-step chirp convolution finishes its rows itself where its columns fit one lane (register rows,
+// M1 <= 24), one peak per row is asked for and the threshold needs no histograms ('adaptive', or 'median' with a multiplier in 0 .. 2)
+bool Engine::fourstep_can_finish(const Plan& pl, const pal_phat_params& prm) const {
+  const Conv& c = pl.inv;
+  static const bool off = getenv("PAL_FIN_FOUR") == nullptr || atoi(getenv("PAL_FIN_FOUR")) == 0;   // opt-in: measured 0.38 against 0.49 M pairs/s for the stored rows + statistics launches
+  const bool nohist = prm.threshold_method > 0 || (prm.threshold_multiplier >= 0 && prm.threshold_multiplier <= 2.0 && getenv("PAL_FIN_HIST") == nullptr);
+  return fin_cols && !off && c.reg && c.M1() <= 24 && prm.num_peaks == 1 && nohist && pl.nout == pl.n;
+}
+
+int Engine::fourstep_pair_group_fin(const Plan& pl, const cd* W, int G, int rows, const int* zero_rows, const pal_phat_params& prm, int n2,
+                                    pal_pair_record* table, int* need, int slot, hipStream_t on) {
+  Engine* e = this;
+  const Conv& c = pl.inv;
+  const int N2 = 1 << c.l2, M1 = c.M1();
+  const int nblk = ((N2 + kColsOwn - 1) / kColsOwn + 3) / 4;
+  PeakArgs a;
+  FinArgs fa;
+  unsigned nwg = 0;
+  PAL_TRY(fin_setup(pl, rows, nblk, M1, N2, prm, n2, table, need, slot, on, a, fa, nwg, G));
+  {
+    char name[48];
+    snprintf(name, sizeof name, "k_colsreg_fin<%d>", M1);
+    ProfScope ps(this, name, on);
+    FinSrc src{W, nullptr, nullptr, c.twA, c.twB, pl.w};
+    PAL_TRY(fin_serialize(on));
+    PAL_SWITCH_M1(M1, c.l2, k_pfa_cols_fin<kColsFourStep, MM, LR, false, false, 4><<<dim3(nwg), dim3(256), 0, on>>>(src, M1, N2, G, 1, nblk, zero_rows, a, fa, rows));
+    PAL_HIP(hipGetLastError());
+    PAL_TRY(fin_done(on));
+  }
+  return PAL_OK;
+}
+
+int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, const int* zero_rows,
+                               const pal_phat_params& prm, int n2, pal_pair_record* table, int* need, int slot, hipStream_t on) {
+  const Pfa& f = pl.pfa;
+  const bool shortcols = f.nch <= 1;                           // short column DFTs (N1 <= 23): the four wavefronts of a block are four strips
+  const int nblk = (f.n2 + (shortcols ? 4 : 1) * kColsOwn - 1) / ((shortcols ? 4 : 1) * kColsOwn);
+  PeakArgs a;
+  FinArgs fa;
+  unsigned nwg = 0;
+  PAL_TRY(fin_setup(pl, rows, nblk, f.n1, f.n2, prm, n2, table, need, slot, on, a, fa, nwg, G));
+  static const bool want_stamps = getenv("PAL_DEBUG_STAMPS") != nullptr;
   PAL_TRY(pfa_rows(pl, permuted, quads, G, Y, on));
   {
     ProfScope ps(this, "k_pfa_cols_fin", on);
@@ -459,6 +517,7 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
     const bool hist = !(a.method > 0 || fa.cheb);
     const int nw = f.nch == 2 ? 2 : 4;
     FinSrc src{Y, f.T, static_cast<const Rader89Tab*>(f.r89), nullptr, nullptr, nullptr};
+    PAL_TRY(fin_serialize(on));
 #define PAL_COLS_FIN(MODE, HI, FU, NW) k_pfa_cols_fin<MODE, kPfaTC, kPfaUnr, HI, FU, NW><<<grid, dim3(64 * NW), 0, on>>>(src, f.n1, f.n2, G, f.nch, nblk, zero_rows, a, fa, rows)
     if (shortcols) { if (hist) PAL_COLS_FIN(kColsStrips, true, false, 4); else PAL_COLS_FIN(kColsStrips, false, false, 4); }
     else if (f.r89 && full && nw == 4) { if (hist) PAL_COLS_FIN(kColsRader89, true, true, 4); else PAL_COLS_FIN(kColsRader89, false, true, 4); }
@@ -471,6 +530,7 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
     }
 #undef PAL_COLS_FIN
     PAL_HIP(hipGetLastError());
+    PAL_TRY(fin_done(on));
   }
   if (want_stamps) {                                           // diagnostics: phase times of this launch (synchronises)
     std::vector<unsigned long long> hst(size_t(nwg) * 8);

@@ -125,9 +125,13 @@ __device__ __forceinline__ void ld_agent16(const double* p, double& a, double& b
 }
 constexpr double kEpochUnit = 4294967296.0;                    // 2^32: an entry's second word = epoch x 2^32 + (index + 1)
 
-// has another block given up waiting?  (then the call has failed and nobody waits any longer)
-__device__ __forceinline__ bool call_failed(const int* status) { return (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4) != 0; }
-constexpr int kSpinLimit = 1 << 16;                            // polls of a bounded wait (a fraction of a second; siblings arrive within microseconds)
+// Every wait is bounded, and giving up is not an error: a block that does not see its siblings' maxima in time publishes its results
+// marked `abandoned` (the transform's rows are then flagged and resolved from stored rows at the end of the call), the
+// finishing block that does not see its siblings' results flags the rows itself.  Siblings normally arrive within
+// microseconds; the bound matters when finishing passes of several streams fill every workgroup slot of the device with
+// blocks whose siblings then find no slot (possible in principle, never seen with 16 blocks per transform; seen with 34):
+// the waiting blocks give up after a few milliseconds, leave, and the late siblings find the maxima they need.
+constexpr int kSpinLimit = 1 << 11;
 
 // ---- the finishing block: one row from the blocks' published results (all LANES lanes, uniform control flow) ----
 template <int LANES>
@@ -141,6 +145,7 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
   int imax = -1, mb = -1;
   double hw = 0, hm = 0, platw = -INFINITY;
   int mw = -1, mm = -1;
+  bool abandoned = false;                                      // a block gave up waiting for the row's argmax: its window sums are missing
   {
     const double* em = fa.emax + size_t(row) * S * 8;
     for (int q = tid; q < S * 4; q += LANES) {
@@ -157,6 +162,7 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
     plat = fmax(plat, pt.plat);
     s1 += pt.s1; s2 += pt.s2; a1 += pt.a1;
     w1 += pt.w1; w2 += pt.w2;
+    abandoned = abandoned || pt.pad != 0;
     if (windowed) {
       if (pt.mw >= 0 && (mw < 0 || higher(pt.hw, pt.mw, hw, mw))) { hw = pt.hw; mw = pt.mw; }
       if (pt.mm >= 0 && (mm < 0 || higher(pt.hm, pt.mm, hm, mm))) { hm = pt.hm; mm = pt.mm; }
@@ -228,6 +234,7 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
   bool flag = false;                                           // the row needs its samples: stored-row path at the end of the call
   int why = 0;                                                 // (diagnostics: which rule flagged it)
   if (imax < 0 || imax >= n) { imax = 0; flag = true; why |= 1; }
+  if (__syncthreads_or(abandoned ? 1 : 0)) { flag = true; why |= 1; }
   // a tie that may outrank the best strict peak (plateaus are resolved from the stored row)
   if (plat > -INFINITY && (mb < 0 || plat >= hb)) { flag = true; why |= 2; }
   if (windowed && platw > -INFINITY && (mw < 0 || platw >= hw)) { flag = true; why |= 4; }
@@ -712,6 +719,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
   }
   // ---- phase 2: the siblings' maxima (published long ago), then the SNR window sums of this block's samples
   stamp();                                                     // 3: pass B
+  if (tid == 0) s_flag = 0;                                    // (1: a wavefront gave up waiting for the siblings' maxima)
+  __syncthreads();
   if (wave < 2 && 2 * g + wave < rows) {
     const int row = 2 * g + wave;
     double bv = 0;
@@ -726,13 +735,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
       for (;;) {                                               // (the entry of this launch: its second word carries the launch number)
         ld_agent16(em + 2 * q, v, code);
         if (floor(code / kEpochUnit) == want) break;
-        if (++spins > kSpinLimit || ((spins & 255) == 0 && call_failed(fa.status))) { late = true; break; }
-        __builtin_amdgcn_s_sleep(4);
+        if (++spins > kSpinLimit) { late = true; break; }
+        __builtin_amdgcn_s_sleep(8);
       }
       const int i = int(code - want * kEpochUnit) - 1;
       if (!late && i >= 0 && i < n && (bi < 0 || arg_better<0>(v, i, bv, bi))) { bv = v; bi = i; }
     }
-    if (__ballot(late) && lane == 0) atomicOr(fa.status, 4);
+    const bool gave_up = __ballot(late) != 0;
+    if (gave_up && lane == 0) { s_flag = 1; atomicAdd(fa.status + 13, 1); }
     wave_arg63(bv, bi, [](double v1, int i1, double v2, int i2) { return arg_better<0>(v1, i1, v2, i2); });
     if (lane == 63) s_imax[wave] = bi;
   }
@@ -769,7 +779,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
     pt.hb = pt.plat = pt.platw = -INFINITY;
     pt.vmin = INFINITY;
     pt.mb = pt.mw = pt.mm = -1;
-    pt.pad = 0;
+    pt.pad = s_flag;                                           // 1: the window sums are not valid (the block gave up waiting)
     pt.s1 = pt.s2 = pt.a1 = pt.hw = pt.hm = pt.w1 = pt.w2 = 0;
     for (int w = 0; w < NW; ++w) {
       const FinPartial x = res[w][r];
@@ -797,11 +807,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
     for (int q = tid; q < nblk - 1; q += LANES) {
       int spins = 0;
       while (ld_agent(fa.done + size_t(g) * nblk + q) != fa.epoch) {
-        if (++spins > kSpinLimit || ((spins & 255) == 0 && call_failed(fa.status))) { late = true; break; }
-        __builtin_amdgcn_s_sleep(4);
+        if (++spins > kSpinLimit) { late = true; break; }
+        __builtin_amdgcn_s_sleep(8);
       }
     }
-    if (__syncthreads_or(late ? 1 : 0) && tid == 0) atomicOr(fa.status, 4);
+    if (__syncthreads_or(late ? 1 : 0)) {                     // the siblings' results are not there: both rows go through the stored-row path
+      if (tid < 2 && 2 * g + tid < rows) { fa.need[2 * g + tid] = 1; atomicAdd(fa.status + 4, 1); atomicAdd(fa.status + 13, 1); }
+      return;
+    }
   }
   FinShared& fsh = *reinterpret_cast<FinShared*>(lds_big);
 #pragma nounroll
