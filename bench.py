@@ -199,6 +199,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: no HIP events around the kernels (roofline kernel block = null)")
     ap.add_argument("--event-every", type=int, default=5, help="HIP events around every n-th launch group (1 = all)")
+    ap.add_argument("--split", choices=["frames", "pairs"], default="frames",
+                    help="frames: every rank owns its own frames (weak scaling); pairs: ONE frame's ordered pair list is block-partitioned "
+                         "over the ranks, spectra recomputed on every rank (strong scaling of a single large frame, SURVEY 8e: C4)")
+    ap.add_argument("--require-rccl", action="store_true", help="exit non-zero when the per-step gather cannot run on RCCL (N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -213,7 +217,10 @@ def main() -> None:
     med = None if args.max_expected_delay < 0 else args.max_expected_delay
 
     from pyaudiolocalization_amd.synthetic import metric_frames
-    frames = metric_frames(b, m, length, first=rank * b)          # this rank's own frames (weak scaling)
+    split_pairs = args.split == "pairs"
+    if split_pairs:
+        b = 1                                                     # ONE frame, the same on every rank; its pair list is block-partitioned
+    frames = metric_frames(b, m, length, first=0 if split_pairs else rank * b)   # this rank's own frames (weak scaling) / the shared frame
 
     # ---- CPU baseline first: host cores only, before this process initialises the GPU -------------------------------
     cpu, want, cm = None, None, 0
@@ -238,7 +245,22 @@ def main() -> None:
 
     d_frames = eng.alloc(frames.nbytes)
     eng.upload(d_frames, frames)
-    tbytes = b * pairs * RECORD.itemsize
+    lo, hi = 0, pairs
+    d_pairs = 0
+    if split_pairs:
+        from pyaudiolocalization_amd.distributed import shard_pairs
+        lo, hi = shard_pairs(m, rank, world)
+        if min(shard_pairs(m, r, world)[1] - shard_pairs(m, r, world)[0] for r in range(world)) <= 0:
+            raise SystemExit("more ranks than pairs")
+        # equal blocks for the all-gather: every rank's block is padded to the largest one (repeating its last pair)
+        blk = max(shard_pairs(m, r, world)[1] - shard_pairs(m, r, world)[0] for r in range(world))
+        mine = pair_list(m)[lo:hi]
+        mine = np.concatenate([mine, np.repeat(mine[-1:], blk - len(mine), axis=0)]).astype(np.int32)
+        d_pairs = eng.alloc(mine.nbytes)
+        eng.upload(d_pairs, np.ascontiguousarray(mine))
+        tbytes = blk * RECORD.itemsize
+    else:
+        tbytes = b * pairs * RECORD.itemsize
     d_table = eng.alloc(tbytes)
     d_all = eng.alloc(tbytes * world) if world > 1 else 0
 
@@ -261,8 +283,12 @@ def main() -> None:
         dist.all_gather_object(flags, gather)
         if any(f != "rccl-allgather" for f in flags) and gather == "rccl-allgather":
             gather = "gloo-host"
+        if args.require_rccl and gather != "rccl-allgather":
+            print(f"[rank {rank}] --require-rccl: the gather would run on '{gather}'", file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(3)
 
-    host_table = np.zeros((b, pairs), dtype=RECORD)
+    host_table = np.zeros((blk,) if split_pairs else (b, pairs), dtype=RECORD)
 
     # The frames are independent: the pair tables of a step need no exchange to be computed.  Where RCCL is up,
     # every step still ends with ONE all-gather of the 48-byte records on the engine's communicator (6 MB per rank: the
@@ -270,7 +296,10 @@ def main() -> None:
     # gathered ONCE through gloo host tensors after it (said in config.gather): a host round trip per step would measure the
     # loopback socket, not the path.
     def step() -> None:
-        eng.gcc_phat_all_pairs_dev(d_frames, b, m, length, prm, d_table)
+        if split_pairs:
+            eng.gcc_phat_pairs_dev(d_frames, m, length, d_pairs, blk, prm, d_table)
+        else:
+            eng.gcc_phat_all_pairs_dev(d_frames, b, m, length, prm, d_table)
         if gather == "rccl-allgather":
             eng.all_gather_dev(d_table, d_all, tbytes)
 
@@ -299,13 +328,20 @@ def main() -> None:
         elapsed = float(t.item())
 
     eng.download(host_table, d_table)
+    gather_timed = gather == "rccl-allgather"                      # the per-step exchange ran inside the timed region
     if gather.startswith("gloo-host"):
-        from pyaudiolocalization_amd.distributed import gather_tables_torch
-        full = gather_tables_torch(host_table, b * world, rank, world)
-        if full is not None and len(full) != b * world:
-            raise RuntimeError("gathered table has the wrong number of frames")
+        if split_pairs:
+            from pyaudiolocalization_amd.distributed import gather_blocks_torch
+            full = gather_blocks_torch(host_table, [blk] * world)
+            if len(full) != blk * world:
+                raise RuntimeError("gathered table has the wrong number of pairs")
+        else:
+            from pyaudiolocalization_amd.distributed import gather_tables_torch
+            full = gather_tables_torch(host_table, b * world, rank, world)
+            if full is not None and len(full) != b * world:
+                raise RuntimeError("gathered table has the wrong number of frames")
         gather += " - once, after the timed region"
-    total_pairs = args.steps * b * pairs * world
+    total_pairs = args.steps * (pairs if split_pairs else b * pairs * world)     # pairs: the ONE frame's list, whatever the rank count
     value = total_pairs / elapsed
 
     # ---- per-kernel durations: live (HIP events inside the timed region, three streams share the CUs) and alone
@@ -320,7 +356,7 @@ def main() -> None:
         cal = None
         try:
             cal = Engine(0 if share else local_rank)
-            cb = min(b, max(1, -(-2 * eng.pair_group_size(length) // pairs)))       # frames that fill one launch group
+            cb = 1 if split_pairs else min(b, max(1, -(-2 * eng.pair_group_size(length) // pairs)))       # frames that fill one launch group
             one = frames[:cb]
             d_one, d_tab = cal.alloc(one.nbytes), cal.alloc(cb * pairs * RECORD.itemsize)
             cal.upload(d_one, one)
@@ -427,7 +463,7 @@ def main() -> None:
 
     # ---- parity sample against the CPU oracle's rows computed above ------------------------------------------------
     parity = None
-    if want is not None:
+    if want is not None and not split_pairs:
         full = pair_list(m)
         pick = np.flatnonzero((full[:, 0] < cm) & (full[:, 1] < cm))
         got = host_table[0][pick]
@@ -449,13 +485,15 @@ def main() -> None:
                       else f"mic-pair GCC-PHAT correlations/s @{fs / 1000:g}kHz·{length / fs:g}s",
             "value": round(value, 1), "unit": "pair-correlations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if split_pairs else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{cfg['label']}: {b} frame(s)/step/GPU x {m} mics x {length} samples @ {fs:g} Hz, "
                                    f"{pairs} pairs/frame, max_expected_delay={med}; {route}",
                        "name": args.config, "frames_per_step_per_gpu": b, "mics": m, "samples": length, "pairs_per_frame": pairs,
                        "fused_column_statistics": os.environ.get("PAL_FUSED", "default"),
                        "finishing_column_pass": os.environ.get("PAL_FIN", "default"), "rader_columns": os.environ.get("PAL_R89", "default"),
-                       "gather": gather, "parallelism": f"frames sharded over {world} GPU(s)"},
+                       "gather": gather, "gather_in_timed_region": gather_timed if world > 1 else None, "split": args.split,
+                       "parallelism": (f"pair list of one frame block-partitioned over {world} GPU(s), spectra recomputed per rank" if split_pairs
+                                       else f"frames sharded over {world} GPU(s)")},
             "roofline": roofline, "roofline_fp64": roofline_fp64, "binding_roofline": binding,
             "cpu_baseline": cpu, "parity": parity, "kernels_ms": kernels,
             "kernels_alone_us": {k: round(v * 1e3, 2) for k, v in alone_avg.items()},

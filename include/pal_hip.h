@@ -37,7 +37,7 @@ extern "C" {
 #define PAL_ERR_MATERIAL (-7)    /* pal_image_sources reached a plane whose material is undefined
                                     (utils.py:93-96); *count holds the plane index            */
 
-#define PAL_MAX_PEAKS 16
+#define PAL_MAX_PEAKS 256
 
 /* branch bits of the peak-selection fallback chain (utils.py:153-172) */
 #define PAL_BR_ALT_THRESHOLD 1

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAL_LIB_PATH") or os.path.join(_HERE, "libpal_hip.so")   # (PAL_LIB_PATH: A/B builds, tools/build_variant.sh)
 
-PAL_MAX_PEAKS = 16
+PAL_MAX_PEAKS = 256
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_INTERNAL, ERR_COMM, ERR_MATERIAL = -1, -2, -3, -4, -5, -6, -7
 BR_ALT_THRESHOLD, BR_ARGMAX_NO_PEAKS, BR_WINDOW_RETRY, BR_ARGMAX_WINDOW = 1, 2, 4, 8
 

@@ -68,6 +68,8 @@ struct PeakArgs {
   double* glist;                         // [rows][kList] bracket values
   int* gcount;                           // [rows] fill of glist (> kList: overflow, the finish kernel re-reads the row)
   unsigned long long* stamps;            // diagnostics (PAL_DEBUG_STAMPS=1): [rows][8] 100 MHz clock reads of the finish launch
+  int memo_cap, stack_cap;               // capacities of the on-chip memo / stack of the distance rule (PAL_DEBUG_MEMO shrinks them: tests of the slow path)
+  unsigned* bits;                        // [rows][2][(n + 31) / 32] scratch bitmaps of the exact slow path of the distance rule (peaks.hip resolve_slow)
 };
 
 __device__ __forceinline__ bool higher(double h1, int m1, double h2, int m2) {   // priority(h1,m1) > priority(h2,m2)

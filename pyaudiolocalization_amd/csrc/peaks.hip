@@ -355,7 +355,7 @@ __device__ int memo_find(const Shared& s, int pos) {
 }
 
 // returns 1 kept, 0 suppressed, -1 overflow; workgroup-uniform control flow
-__device__ __forceinline__ int resolve(const double* c, int n, int dist, int tid, Shared& s, int pos0, double h0) {
+__device__ __forceinline__ int resolve(const double* c, int n, int dist, int tid, Shared& s, int pos0, double h0, int memo_cap, int stack_cap) {
   if (tid == 0) { s.stack_n = 1; s.stack_pos[0] = pos0; s.stack_h[0] = h0; s.flag = 0; }
   __syncthreads();
   for (int guard = 0; guard < 100000; ++guard) {
@@ -391,7 +391,7 @@ __device__ __forceinline__ int resolve(const double* c, int n, int dist, int tid
     barg<2>(bh, bm, s, tid);
     if (tid == 0) {
       if (any_kept || bm < 0) {
-        if (s.memo_n < kMemo) {
+        if (s.memo_n < memo_cap) {
           s.memo_pos[s.memo_n] = p;
           s.memo_kept[s.memo_n] = any_kept ? 0 : 1;
           ++s.memo_n;
@@ -399,7 +399,7 @@ __device__ __forceinline__ int resolve(const double* c, int n, int dist, int tid
           s.flag = 1;
         }
         s.stack_n = depth - 1;
-      } else if (depth < kStack) {
+      } else if (depth < stack_cap) {
         s.stack_pos[depth] = bm;
         s.stack_h[depth] = bh;
         s.stack_n = depth + 1;
@@ -416,6 +416,53 @@ __device__ __forceinline__ int resolve(const double* c, int n, int dist, int tid
   return st < 0 ? -1 : st;
 }
 
+// ---- the same decision without capacity limits: scipy's greedy pass itself, over every peak above the candidate ----
+// resolve() answers "is the candidate kept?" depth first with an on-chip memo (1024 resolved peaks, 64 frames): enough for any
+// PHAT row met so far, but utils.py:152 has no such limit.  When it overflows, the row takes this path: a bitmap of the row's
+// peaks (scipy's _local_maxima_1d, plateau midpoints included) and a bitmap of the positions already suppressed, both in
+// global memory; then _select_by_peak_distance literally - the highest peak not yet suppressed is kept and suppresses every
+// position closer than `distance` - until the candidate's priority is reached.  Milliseconds per row, exact for any input.
+__device__ int resolve_slow(const double* c, int n, int dist, int tid, Shared& s, unsigned* bits, int pos0, double h0) {
+  const int words = (n + 31) / 32;
+  unsigned* peak = bits;                                       // bit m: sample m is a peak
+  unsigned* gone = bits + words;                               // bit m: suppressed (or kept: not to be found again)
+  for (int w = tid; w < words; w += kT) {
+    unsigned pk = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int m = 32 * w + b;
+      if (m < 1 || m > n - 2) continue;
+      const double xl = c[m - 1], x = c[m], xr = c[m + 1];
+      double hm;
+      if ((xl < x && xr < x) || ((xl == x || xr == x) && peak_mid(c, n, m, hm))) pk |= 1u << b;
+    }
+    peak[w] = pk;
+    gone[w] = 0;
+  }
+  __syncthreads();
+  for (int guard = 0; guard < n; ++guard) {
+    // the highest peak above the candidate that is still standing
+    double bh = 0;
+    int bm = -1;
+    for (int w = tid; w < words; w += kT) {
+      unsigned live = peak[w] & ~gone[w];
+      while (live) {
+        const int b = __ffs(int(live)) - 1;
+        live &= live - 1;
+        const int m = 32 * w + b;
+        const double hm = c[m];
+        if (higher(hm, m, h0, pos0) && (bm < 0 || higher(hm, m, bh, bm))) { bh = hm; bm = m; }
+      }
+    }
+    barg<2>(bh, bm, s, tid);
+    if (bm < 0) break;                                         // nothing above the candidate is left: it is kept
+    if (bm - pos0 < dist && pos0 - bm < dist) return 0;        // a kept higher peak closer than `distance`
+    const int lo = bm - (dist - 1) > 0 ? bm - (dist - 1) : 0, hi = bm + (dist - 1) < n - 1 ? bm + (dist - 1) : n - 1;
+    for (int m = lo + tid; m <= hi; m += kT) atomicOr(&gone[m >> 5], 1u << (m & 31));
+    __syncthreads();
+  }
+  return 1;
+}
+
 __device__ __forceinline__ bool in_window(int m, int n2, double fs, double med) {
   return fabs(double(m - (n2 - 1)) / fs) <= med;       // abs(time_lags[k]) <= max_expected_delay (utils.py:163)
 }
@@ -425,6 +472,8 @@ __device__ __forceinline__ bool in_window(int m, int n2, double fs, double med) 
 struct SelArgs {            // by value: a reference to the kernel's argument struct would force it (and the address
   int n, n2, dist, num_peaks;   // space of every pointer in it) through private memory
   double fs, med;
+  unsigned* bits;           // this row's bitmaps for resolve_slow
+  int memo_cap, stack_cap;
 };
 
 __device__ __forceinline__ bool next_candidate(const SelArgs a, const double* c, int tid, Shared& s, double thr, bool windowed, int wlo,
@@ -484,7 +533,13 @@ __device__ __forceinline__ int select_peaks(const SelArgs a, const double* c, in
       if (!next_candidate(a, c, tid, s, tlo, windowed, wlo, whi, bound_h, bound_m, ch, cm)) break;
       if (!(ch >= thi)) return -2;                             // inside the threshold's interval (never when tlo == thi)
     }
-    const int st = resolve(c, a.n, a.dist, tid, s, cm, ch);
+    int st = resolve(c, a.n, a.dist, tid, s, cm, ch, a.memo_cap, a.stack_cap);
+    if (st < 0 && a.bits) {                                              // memo or stack exhausted: the exact slow path, then a fresh memo
+      st = resolve_slow(c, a.n, a.dist, tid, s, a.bits, cm, ch);
+      __syncthreads();
+      if (tid == 0) s.memo_n = 0;
+      __syncthreads();
+    }
     if (st < 0) return -1;
     if (st == 1) {                                             // (the list lives in LDS: 48 registers per lane otherwise)
       if (tid == 0) { s.sel_pos[count] = cm; s.sel_h[count] = ch; }
@@ -1120,7 +1175,7 @@ __device__ __forceinline__ void finish_row(const PeakArgs& a, pal_pair_record* t
     wlo = flo > 1.0 ? (flo < double(n) ? int(flo) : n) : 1;
     whi = fhi < double(n - 2) ? (fhi > -1.0 ? int(fhi) : -1) : n - 2;
   }
-  const SelArgs sa{n, a.n2, a.dist, a.num_peaks, a.fs, a.med};
+  const SelArgs sa{n, a.n2, a.dist, a.num_peaks, a.fs, a.med, a.bits ? a.bits + size_t(row) * 2 * ((n + 31) / 32) : nullptr, a.memo_cap, a.stack_cap};
   // np.mean(np.abs(corr)) (utils.py:155): the alternative threshold of the fallback chain.  The fused column pass sums
   // |x| only for the 'adaptive' method; the (rare) fallback branches sum it from the stored row.
   double mean_abs = ka + a1 / double(n);
@@ -1280,8 +1335,9 @@ int Engine::peaks_setup(const double* corr, size_t stride, int rows, int n, int 
   size_t off_parts = (off_pre + size_t(rows) * sizeof(RowPre) + 127) & ~size_t(127);
   size_t off_list = (off_parts + size_t(rows) * a.splits * sizeof(Partial) + 127) & ~size_t(127);
   // (fused column pass: the segments' histogram windows take the place of the bracket lists)
-  const size_t total = off_list + (a.local_pivots ? size_t(rows) * a.splits * sizeof(BlockHist)
-                                                  : (a.method == 0 ? size_t(rows) * kList * sizeof(double) : 0));
+  const size_t list_bytes = a.local_pivots ? size_t(rows) * a.splits * sizeof(BlockHist) : (a.method == 0 ? size_t(rows) * kList * sizeof(double) : 0);
+  const size_t off_bits = (off_list + list_bytes + 127) & ~size_t(127);
+  const size_t total = off_bits + (corr ? size_t(rows) * 2 * ((size_t(n) + 31) / 32) * sizeof(unsigned) : 0);   // (bitmaps only where rows are stored)
   void* sp = nullptr;
   PAL_TRY(scratch(on == stream2 ? 9 : (on == stream3 ? 12 : 8), total, &sp));
   char* base = static_cast<char*>(sp);
@@ -1290,6 +1346,12 @@ int Engine::peaks_setup(const double* corr, size_t stride, int rows, int n, int 
   a.parts = reinterpret_cast<Partial*>(base + off_parts);
   a.glist = reinterpret_cast<double*>(base + off_list);
   a.bh = reinterpret_cast<BlockHist*>(base + off_list);
+  a.bits = corr ? reinterpret_cast<unsigned*>(base + off_bits) : nullptr;
+  {
+    static const int dbg = getenv("PAL_DEBUG_MEMO") ? atoi(getenv("PAL_DEBUG_MEMO")) : 0;     // (tests: a tiny memo sends every chain to the slow path)
+    a.memo_cap = dbg > 0 && dbg < kMemo ? dbg : kMemo;
+    a.stack_cap = dbg > 0 && dbg < kStack ? dbg : kStack;
+  }
   return PAL_OK;
 }
 

@@ -84,3 +84,62 @@ def test_bench_line_keeps_the_contract():
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and "sample" in cpu
     assert d["parity"]["k_sel_equal"] == d["parity"]["pairs_checked"] == 15
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def _run_bench_ranks(world, args, queue, env_extra):
+    """In a fork-server child (no HIP state): bench.py under torch.distributed.run with `world` ranks on this box."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    queue.put((out.returncode, lines[-1] if lines else "", out.stderr[-3000:]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", ["frames", "pairs"])
+def test_bench_two_ranks_share_the_gpu(split):
+    """The N = 2 line of bench.py, rehearsed on the one-GPU box (PAL_BENCH_SHARE_GPU=1: both ranks on device 0, gather through gloo
+    because RCCL refuses two ranks on one device): rank count, partition, gather transport, and a rate of the right order.  The
+    children come from the fork server that predates every HIP call."""
+    import multiprocessing as mp
+    import conftest
+    conftest.require_forkserver()
+    ctx = mp.get_context("forkserver")
+    queue = ctx.Queue()
+    args = ["--steps", "2", "--warmup", "1", "--mics", "16", "--length", "6000", "--no-cpu-baseline", "--no-kernel-events", "--split", split]
+    if split == "frames":
+        args += ["--frames", "2"]
+    p = ctx.Process(target=_run_bench_ranks, args=(2, args, queue, {"PAL_BENCH_SHARE_GPU": "1"}))
+    p.start()
+    rc, line, err = queue.get(timeout=900)
+    p.join(timeout=60)
+    assert rc == 0, err
+    d = json.loads(line)
+    assert CONTRACT <= set(d) | {"cpu_baseline"}
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    assert d["config"]["gather"].startswith("gloo-host") and d["config"]["gather_in_timed_region"] is False
+    assert d["config"]["split"] == split and d["scaling"] == ("strong" if split == "pairs" else "weak")
+    pairs = 16 * 15 // 2
+    units = pairs if split == "pairs" else 2 * pairs * 2                     # per step: one frame's list, or 2 frames on each of 2 ranks
+    assert abs(d["value"] - units / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_require_rccl_refuses_the_fallback():
+    """--require-rccl: a scaling run must not report the gloo fallback silently (the shared-GPU rehearsal cannot bring RCCL up)."""
+    import multiprocessing as mp
+    import conftest
+    conftest.require_forkserver()
+    ctx = mp.get_context("forkserver")
+    queue = ctx.Queue()
+    args = ["--steps", "1", "--warmup", "0", "--mics", "8", "--length", "3000", "--frames", "1", "--no-cpu-baseline", "--no-kernel-events", "--require-rccl"]
+    p = ctx.Process(target=_run_bench_ranks, args=(2, args, queue, {"PAL_BENCH_SHARE_GPU": "1"}))
+    p.start()
+    rc, line, err = queue.get(timeout=900)
+    p.join(timeout=60)
+    assert rc != 0 and "--require-rccl" in err, (rc, err[-500:])

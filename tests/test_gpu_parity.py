@@ -361,12 +361,38 @@ def test_num_peaks_and_methods(engine):
         assert int(rec["branch"]) == br
 
 
+def test_many_peaks_and_the_exact_slow_path_of_the_distance_rule(monkeypatch):
+    """utils.py:152,176-179 put no limit on num_peaks or on chains of the distance rule.  64 peaks at fs = 192 kHz (distance 192)
+    against the oracle; then the same selections with the on-chip memo / stack shrunk to two entries (PAL_DEBUG_MEMO=2), which
+    sends every suppression chain through the exact slow path (scipy's greedy pass over bitmaps in global memory)."""
+    from pyaudiolocalization_amd import Engine
+    rng = np.random.default_rng(13)
+    cases = []
+    for trial in range(6):
+        n = int(rng.integers(6000, 20000))
+        a = rng.standard_normal(n)
+        b = np.roll(a, int(rng.integers(-50, 50))) + [0.3, 1.0, 3.0][trial % 3] * rng.standard_normal(n)
+        cases.append((a, b, [192000.0, 48000.0][trial % 2], [64, 200, 7][trial % 3], [None, 0.01][trial % 2], ["median", "adaptive"][trial // 3]))
+    for memo in ("", "2"):
+        if memo:
+            monkeypatch.setenv("PAL_DEBUG_MEMO", memo)
+        eng = Engine(0)
+        try:
+            for a, b, fs, npk, med, meth in cases:
+                ks, rec, corr = eng.get_time_delays_phat(a, b, fs, npk, meth, 0.5, med)
+                want, br = O.select_peaks(O.phat_correlation(a, b), a.size, fs, npk, meth, 0.5, med)
+                assert np.array_equal(ks, want), (memo, npk, ks[:8], want[:8])
+                assert int(rec["branch"]) == br
+        finally:
+            eng.close()
+
+
 def test_argument_errors(engine):
     x = np.ones(64)
     with pytest.raises(ValueError):
         engine.get_time_delays_phat(x, x, 500.0)                  # int(fs*0.001) == 0 -> find_peaks raises
     with pytest.raises(ValueError):
-        engine.get_time_delays_phat(x, x, 48000.0, num_peaks=17)
+        engine.get_time_delays_phat(x, x, 48000.0, num_peaks=257)
     with pytest.raises(ValueError):
         engine.gcc_phat_all_pairs(np.ones((1, 64)), 48000.0)      # needs two mics
     with pytest.raises(ValueError):
