@@ -80,9 +80,15 @@ int pal_synchronize(pal_handle h);
  * pipeline (two pairs per transform) 240 where one workspace slot stays below 1 GiB, 32 at least */
 int pal_set_chunk(pal_handle h, int chunk);
 /* Plans (chirps, chirp spectra, prime-factor tables: a few MB per transform length) are built on first use and cached
- * per length, at most 32 of them (PAL_MAX_PLANS), least recently used out first; pal_clear_plans drops them all now
+ * per length, at most 64 of them (PAL_MAX_PLANS, pal_set_max_plans), least recently used out first; pal_clear_plans drops them all now
  * (after draining the engine's streams).  The reference keeps no such state (numpy.fft plans are per call). */
 int pal_clear_plans(pal_handle h);
+/* Bound of the plan caches (2 .. 4096; 8-16 MB of HBM per plan).  A stream whose frames come in more distinct lengths than the
+ * bound, visited cyclically, would rebuild a plan on every visit (least recently used out first is the worst case for a
+ * cycle): stream.tdoa_stream raises the bound to the number of lengths of its batch.  pal_plan_stats: plans built and plans
+ * evicted since the engine was created (a run that rebuilds plans shows it there). */
+int pal_set_max_plans(pal_handle h, int max_plans);
+int pal_plan_stats(pal_handle h, int64_t* built, int64_t* evicted);
 /* packed transforms (pairs / 2) one launch group of the all-pairs pipeline carries for frames of L samples */
 int pal_pair_group_size(pal_handle h, int L, int32_t* transforms);
 
@@ -167,12 +173,16 @@ int pal_xcorr_vs_ref(pal_handle h, const double* rows, int R, int N, int ref_idx
  * utils.py:428-451 stay host work, as in pal_xcorr_vs_ref).  All `d_` pointers come from pal_device_alloc.
  *
  * pal_simulate_multipath_dev: as pal_simulate_multipath with d_base[B][nbase], d_delays / d_gains[B][M][K], d_out[B][M][out_len].
- * pal_sync_measure_dev: per frame b of d_rows[B][M][N]: ref_idx[b] = argmax of the row energies (utils.py:413-414), then
+ * pal_row_energies_dev: energy[r] = sum of squares of row r of d_rows[R][N] (device summation order: last-bit differences
+ *   from numpy's np.sum(sig**2) - the caller settles near-ties of utils.py:413-414 with numpy itself, engine.sync_measure_dev).
+ * pal_sync_measure_dev: per frame b of d_rows[B][M][N]: ref_idx[b] (IN / OUT: >= 0 on entry = use this reference microphone;
+ *   < 0 = argmax of the device's row energies, utils.py:413-414), then
  *   pal_xcorr_vs_ref of the frame's rows against that row: kpk[B][M], win5[B][M][5], pkabs[B][M], refpk[B] (host arrays).
  * pal_align_rows_dev: utils.py:448-456 - d_out[r][pad_left[r] + i] = d_rows[r][i], zeros elsewhere (rows of Lout samples).
  * pal_filtfilt_dev / pal_wiener3_dev: as pal_filtfilt / pal_wiener3 on rows in HBM (b, a, zi stay host arrays). */
 int pal_simulate_multipath_dev(pal_handle h, const double* d_base, int B, int nbase, double fs, int total_samples,
                                const double* d_delays, const double* d_gains, int M, int K, int trim_len, double* d_out);
+int pal_row_energies_dev(pal_handle h, const double* d_rows, int R, int N, double* energy);
 int pal_sync_measure_dev(pal_handle h, const double* d_rows, int B, int M, int N, int32_t* ref_idx, int32_t* kpk,
                          double* win5, double* pkabs, double* refpk);
 int pal_align_rows_dev(pal_handle h, const double* d_rows, int R, int N, const int32_t* pad_left, int Lout, double* d_out);

@@ -48,6 +48,8 @@ SIGNATURES = {
     "pal_last_error": (C.c_char_p, [_H]),
     "pal_synchronize": (C.c_int, [_H]),
     "pal_clear_plans": (C.c_int, [_H]),
+    "pal_set_max_plans": (C.c_int, [_H, C.c_int]),
+    "pal_plan_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pal_set_chunk": (C.c_int, [_H, C.c_int]),
     "pal_pair_group_size": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int32)]),
     "pal_device_alloc": (C.c_int, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -77,6 +79,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_double)]),
     "pal_simulate_multipath_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pal_row_energies_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pal_sync_measure_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "pal_align_rows_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

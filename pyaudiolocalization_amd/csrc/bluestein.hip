@@ -434,6 +434,7 @@ int Engine::get_plan(int n, int lin, int nout, Plan** out) {
     PAL_HIP(hipStreamSynchronize(stream3));
     free_plan(old->second);
     plans.erase(old);
+    ++plans_evicted;
   }
   Plan pl;
   pl.n = n;
@@ -460,6 +461,7 @@ int Engine::get_plan(int n, int lin, int nout, Plan** out) {
     return rc;
   }
   pl.used = ++plan_clock;
+  ++plans_built;
   auto ins = plans.emplace(key, pl);
   *out = &ins.first->second;
   return PAL_OK;

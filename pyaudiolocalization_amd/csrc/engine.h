@@ -113,7 +113,8 @@ struct Engine {
   std::map<std::tuple<int, int, int>, Plan> plans;   // (n, lin, nout) -> plan
   struct XConv { Conv conv; long long used = 0; };
   std::map<size_t, XConv> xconvs;                    // sequence length -> convolution of pal_xcorr_vs_ref
-  int max_plans = 32;                                // PAL_MAX_PLANS: bound of both caches (least recently used out first)
+  int max_plans = 64;                                // PAL_MAX_PLANS / pal_set_max_plans: bound of both caches (least recently used out first)
+  long long plans_built = 0, plans_evicted = 0;      // pal_plan_stats
   long long plan_clock = 0;
   cd* stage_tw[16] = {};                        // stage-major twiddles per log2 N (<= 14: the big row tiles of pfa_big.h)
   cd* stage_twc[16] = {};                       // the same with a compact last stage (fft_core.h stage_twc_size)

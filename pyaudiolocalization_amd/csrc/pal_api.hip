@@ -326,6 +326,20 @@ int pal_clear_plans(pal_handle h) {
   return e->clear_plans();
 }
 
+int pal_set_max_plans(pal_handle h, int max_plans) {
+  ENGINE(h);
+  if (max_plans < 2 || max_plans > 4096) return e->fail(PAL_ERR_INVALID, "max_plans %d outside 2..4096", max_plans);
+  e->max_plans = max_plans;
+  return PAL_OK;
+}
+
+int pal_plan_stats(pal_handle h, int64_t* built, int64_t* evicted) {
+  ENGINE(h);
+  if (built) *built = e->plans_built;
+  if (evicted) *evicted = e->plans_evicted;
+  return PAL_OK;
+}
+
 int pal_set_chunk(pal_handle h, int chunk) {
   ENGINE(h);
   if (chunk < 0 || chunk > 4096) return e->fail(PAL_ERR_INVALID, "chunk %d outside 0..4096", chunk);

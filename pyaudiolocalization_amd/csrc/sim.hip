@@ -648,6 +648,17 @@ int pal_wiener3_dev(pal_handle h, const double* d_rows, int R, int N, double* d_
   return e->check(hipGetLastError(), "k_wiener3");
 }
 
+int pal_row_energies_dev(pal_handle h, const double* d_rows, int R, int N, double* energy) {
+  ENGINE(h);
+  if (!d_rows || !energy || R < 1 || N < 1) return e->fail(PAL_ERR_INVALID, "bad energy arguments");
+  void* de = nullptr;
+  PAL_TRY(e->scratch(6, size_t(R) * sizeof(double), &de));
+  k_row_energy<<<dim3(R), dim3(kLanes), 0, e->stream>>>(d_rows, size_t(N), N, static_cast<double*>(de));
+  PAL_TRY(e->check(hipGetLastError(), "k_row_energy"));
+  PAL_TRY(e->check(hipMemcpyAsync(energy, de, size_t(R) * sizeof(double), hipMemcpyDeviceToHost, e->stream), "download"));
+  return e->check(hipStreamSynchronize(e->stream), "energy sync");
+}
+
 int pal_sync_measure_dev(pal_handle h, const double* d_rows, int B, int M, int N, int32_t* ref_idx, int32_t* kpk,
                          double* win5, double* pkabs, double* refpk) {
   ENGINE(h);
@@ -662,6 +673,7 @@ int pal_sync_measure_dev(pal_handle h, const double* d_rows, int B, int M, int N
   PAL_TRY(e->check(hipMemcpyAsync(en.data(), de, size_t(R) * sizeof(double), hipMemcpyDeviceToHost, e->stream), "download"));
   PAL_TRY(e->check(hipStreamSynchronize(e->stream), "energy sync"));
   for (int b = 0; b < B; ++b) {
+    if (ref_idx[b] >= 0 && ref_idx[b] < M) continue;            // the caller has chosen (near-ties of the energies settled with numpy)
     int best = 0;
     for (int m = 1; m < M; ++m)
       if (en[size_t(b) * M + m] > en[size_t(b) * M + best]) best = m;      // (NaN never wins: np.argmax would return the NaN row -

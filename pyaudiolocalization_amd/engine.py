@@ -87,6 +87,16 @@ class Engine:
         """Drop every cached transform plan (they are rebuilt on next use; the cache is bounded anyway)."""
         self._check(self._lib.pal_clear_plans(self._h))
 
+    def set_max_plans(self, max_plans: int) -> None:
+        """Bound of the plan caches (least recently used out first); see include/pal_hip.h."""
+        self._check(self._lib.pal_set_max_plans(self._h, int(max_plans)))
+
+    def plan_stats(self):
+        """(plans built, plans evicted) since the engine was created."""
+        b, e = C.c_int64(), C.c_int64()
+        self._check(self._lib.pal_plan_stats(self._h, C.byref(b), C.byref(e)))
+        return b.value, e.value
+
     def pair_group_size(self, length: int) -> int:
         """Packed transforms (two pairs each) per launch group of the all-pairs pipeline for frames of `length` samples."""
         g = C.c_int32()
@@ -277,7 +287,26 @@ class Engine:
     def sync_measure_dev(self, d_rows: int, b: int, m: int, n: int):
         """Per frame: reference microphone (highest energy) and the cross-correlation measurements of every row against it
         -> (ref_idx[B], kpk[B][M], win5[B][M][5], pkabs[B][M], refpk[B]) on the host (a few numbers per row)."""
-        ref = np.zeros(b, dtype=np.int32)
+        # The reference microphone is np.argmax of np.sum(sig**2) (utils.py:413-414).  The device sums in another order: where the two
+        # highest energies of a frame agree to 1e-12 (mirrored geometries, equal rows) those rows come to the host and numpy
+        # itself decides, so that the choice - and with it every shift, pad and length behind it - is the reference's.
+        en = np.zeros(b * m)
+        self._check(self._lib.pal_row_energies_dev(self._h, C.c_void_p(d_rows), int(b * m), int(n), en.ctypes.data))
+        en = en.reshape(b, m)
+        ref = np.full(b, -1, dtype=np.int32)
+        for f in range(b):
+            if not np.all(np.isfinite(en[f])):
+                continue                                            # (NaN rows: the device's rule, as np.argmax)
+            top = float(en[f].max())
+            close = np.flatnonzero(en[f] >= top - 1e-12 * abs(top))
+            if close.size > 1:
+                exact = en[f].copy()
+                row = np.empty(n)
+                for q in close:
+                    self.download(row, d_rows + (f * m + int(q)) * n * 8)
+                    exact[q] = np.sum(row ** 2)
+                exact[np.setdiff1d(np.arange(m), close)] = -np.inf
+                ref[f] = int(np.argmax(exact))
         kpk = np.zeros((b, m), dtype=np.int32)
         win = np.zeros((b, m, 5))
         pk = np.zeros((b, m))

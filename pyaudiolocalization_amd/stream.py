@@ -64,6 +64,11 @@ def tdoa_stream(bases: Sequence[np.ndarray], delays: Sequence[np.ndarray], gains
     by_out: Dict[int, List[int]] = defaultdict(list)                       # frames whose simulated rows have one length
     for f in range(nf):
         by_out[out_len_of(int(totals[f]))].append(f)
+    # Every distinct simulated length and every synchronised length is a transform plan (8-16 MB each), and the batches visit them in
+    # the same order again and again - the worst case for a least-recently-used cache that is smaller than the working set.
+    # The bound follows the workload: simulated lengths + as many synchronised lengths + the correlations of the
+    # synchronisation, with room to spare.
+    eng.set_max_plans(min(4096, max(64, 3 * len(set(int(t) for t in totals)) + 32)))
     for out_len, members in by_out.items():
         for at in range(0, len(members), frames_per_batch):
             group = members[at: at + frames_per_batch]

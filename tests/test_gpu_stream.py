@@ -247,3 +247,26 @@ def test_two_ranks_engine_compute_gloo_gather(engine, mode):
         assert np.array_equal(ref[key], want[key]), key
     for key in ("cmax", "cmin", "snr", "sel_height"):                          # (block borders change a pair's transform partner)
         assert np.allclose(ref[key], want[key], rtol=1e-11, atol=1e-15), key
+
+
+def test_sync_reference_microphone_with_equal_energies(engine):
+    """utils.py:413-414: the reference microphone is np.argmax of np.sum(sig**2).  Mirrored microphones give rows of equal or
+    nearly equal energy; the device's summation order must not decide then - near-ties are settled with numpy's own sum."""
+    rng = np.random.default_rng(41)
+    b, m, n = 3, 8, 6000
+    rows = rng.standard_normal((b, m, n)) * 0.5
+    rows[0, 3] = rng.standard_normal(n) * 2.0                 # frame 0: rows 1, 3, 5 share one energy exactly (1 = -3, 5 = 3): the first wins
+    rows[0, 1] = -rows[0, 3]
+    rows[0, 5] = rows[0, 3]
+    rows[1, 6] = rng.standard_normal(n) * 2.0                 # frame 1: rows 2 and 6 hold the same samples in another order: equal up to rounding
+    rows[1, 2] = rows[1, 6][rng.permutation(n)]
+    rows[2, 4] = rng.standard_normal(n) * 2.0                 # frame 2: a clear winner
+    want = [int(np.argmax([np.sum(r ** 2) for r in rows[f]])) for f in range(b)]
+    d = engine.alloc(rows.nbytes)
+    try:
+        engine.upload(d, np.ascontiguousarray(rows))
+        ref, kpk, win, pk, refpk = engine.sync_measure_dev(d, b, m, n)
+    finally:
+        engine.free(d)
+    assert ref.tolist() == want, (ref.tolist(), want)
+    assert want[0] == 1 and want[2] == 4

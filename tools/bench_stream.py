@@ -65,6 +65,7 @@ print(json.dumps({
                 "max_expected_delay 0.05; device-resident chain (stream.tdoa_stream)",
     "frames_per_s": round(frames / el, 2), "pair_correlations_per_s": round(frames * 2016 / el, 1), "elapsed_s": round(el, 4),
     "distinct_simulated_lengths": len(set(totals)), "distinct_synchronised_lengths": len(set(int(v) for v in lengths)),
+    "plans_built_evicted": list(eng.plan_stats()),
     "host_geometry_s": round(geometry_s, 3), "kernels_ms": kernels,
     "simulate_c2b_s": round(sim_c2b, 5), "simulate_c2b_note": "8 mics x (1 direct + 7 images), 48 kHz x 1 s, host arrays in and out; the reference: 3.29 s (BASELINE.md)",
     "filtfilt_64x24000_s": round(filt64, 5), "filtfilt_note": "Butterworth-5 band-pass, 64 rows x 24000 samples, host arrays in and out"}))
