@@ -379,7 +379,11 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
 bool Engine::pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const {
   const Pfa& f = pl.pfa;
   static const bool strips = getenv("PAL_FIN_STRIPS") != nullptr;
-  return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.n2 >= 256 && (f.nch >= 2 || strips);
+  static const bool dense = getenv("PAL_FIN_DENSE") != nullptr;
+  // Measured over L = 44100 ... 44299 (profiles/r03_c_length_sweep_fin*.csv): the pass wins where the columns are the Rader-89
+  // transform (+2 ... +9 %), and loses 30 - 40 % with the dense column DFT of 25 <= n1 <= 85 (opt-in: PAL_FIN_DENSE=1)
+  const bool cols_ok = f.r89 != nullptr || (dense && f.nch >= 2) || strips;
+  return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.n2 >= 256 && cols_ok;
 }
 
 // The blocks of a finishing pass wait for their siblings (pfa_cols_fin.h).  ONE such launch is deadlock-free (its workgroups are
