@@ -410,9 +410,10 @@ int Engine::fin_setup(const Plan& pl, int rows, int nblk, int grid_rows, int gri
   PAL_TRY(peaks_setup(nullptr, 0, rows, n, n2, prm, nblk, grid_cols, on, a));
   // per-stream scratch of the finishing pass: [done words G x blocks | emax | parts | edge]
   const int Gmax = pair_group(n);
-  const size_t off_emax = (size_t(Gmax) * nblk * sizeof(unsigned) + 127) & ~size_t(127);
+  // (`done` words and FinPartial entries: room for one per WAVEFRONT of a block, pfa_fin_lean.h)
+  const size_t off_emax = (size_t(Gmax) * nblk * 4 * sizeof(unsigned) + 127) & ~size_t(127);
   const size_t off_parts = (off_emax + size_t(2 * Gmax) * nblk * 8 * sizeof(double) + 127) & ~size_t(127);
-  const size_t off_edge = (off_parts + size_t(2 * Gmax) * nblk * sizeof(FinPartial) + 127) & ~size_t(127);
+  const size_t off_edge = (off_parts + size_t(2 * Gmax) * nblk * 4 * sizeof(FinPartial) + 127) & ~size_t(127);
   const size_t total = off_edge + size_t(2 * Gmax) * 4 * grid_rows * sizeof(double);
   void* sp = nullptr;
   PAL_TRY(scratch(16 + slot, total, &sp));
@@ -438,6 +439,7 @@ int Engine::fin_setup(const Plan& pl, int rows, int nblk, int grid_rows, int gri
   fa.edge = reinterpret_cast<double*>(base + off_edge);
   fa.status = status;
   // the lag window |m - (n2 - 1)| / fs <= max_expected_delay (utils.py:163) as sample indices, with the reference's arithmetic
+  fa.pw = 1;
   fa.windowed = std::isnan(prm.max_expected_delay) ? 0 : 1;
   fa.win_lo = 1;
   fa.win_hi = n - 2;
@@ -524,7 +526,7 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
     PAL_TRY(fin_serialize(on));
 #define PAL_COLS_FIN(MODE, HI, FU, NW) k_pfa_cols_fin<MODE, kPfaTC, kPfaUnr, HI, FU, NW><<<grid, dim3(64 * NW), 0, on>>>(src, f.n1, f.n2, G, f.nch, nblk, zero_rows, a, fa, rows)
     if (shortcols) { if (hist) PAL_COLS_FIN(kColsStrips, true, false, 4); else PAL_COLS_FIN(kColsStrips, false, false, 4); }
-    else if (f.r89 && full && nw == 4) { if (hist) PAL_COLS_FIN(kColsRader89, true, true, 4); else PAL_COLS_FIN(kColsRader89, false, true, 4); }
+    else if (f.r89 && full && nw == 4) { if (hist) PAL_COLS_FIN(kColsRader89, true, true, 4); else { fa.pw = 4; PAL_COLS_FIN(kColsRader89, false, true, 4); } }
     else if (nw == 2) {
       if (hist) { if (full) PAL_COLS_FIN(kColsDense, true, true, 2); else PAL_COLS_FIN(kColsDense, true, false, 2); }
       else { if (full) PAL_COLS_FIN(kColsDense, false, true, 2); else PAL_COLS_FIN(kColsDense, false, false, 2); }

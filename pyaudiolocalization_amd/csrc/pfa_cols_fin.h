@@ -62,6 +62,7 @@ struct FinArgs {
   int* status;                    // engine status words (bit 2 of word 0: a wait timed out; word 4: flagged rows)
   int win_lo, win_hi;             // lag window as sample indices, |m - (n2 - 1)| / fs <= max_expected_delay (win_lo > win_hi: empty)
   int windowed;
+  int pw;                         // FinPartial entries and `done` words per column block: 1, or 4 = one per wavefront (pfa_fin_lean.h)
   int cheb;                       // 1: no histograms - the median of |corr| is bounded by sqrt(2 mean(corr^2)) (see fin_row)
   unsigned long long* stamps;     // diagnostics (PAL_DEBUG_STAMPS=1): [workgroup][8] 100 MHz clock reads of lane 0 per phase
 };
@@ -155,8 +156,8 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
       if (i >= 0 && i < n && (imax < 0 || arg_better<0>(v, i, vmax, imax))) { vmax = v; imax = i; }
     }
   }
-  for (int q = tid; q < S; q += LANES) {
-    const FinPartial pt = ld_words(fa.parts + size_t(row) * S + q);
+  for (int q = tid; q < S * fa.pw; q += LANES) {
+    const FinPartial pt = ld_words(fa.parts + size_t(row) * S * fa.pw + q);
     vmin = fmin(vmin, pt.vmin);
     if (pt.mb >= 0 && (mb < 0 || higher(pt.hb, pt.mb, hb, mb))) { hb = pt.hb; mb = pt.mb; }
     plat = fmax(plat, pt.plat);
@@ -374,6 +375,10 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
   }
 }
 
+}  // namespace pal
+#include "pfa_fin_lean.h"
+namespace pal {
+
 // Where the samples of a column block come from
 //   kColsDense     prime-factor grid, dense column DFT: the NW wavefronts are chunks of P1 = TC output indices of ONE 62-column strip
 //   kColsRader89   prime-factor grid, N1 = 89: Rader's 8 x 11 convolution spread over four wavefronts (pfa_rader89.h)
@@ -381,6 +386,11 @@ __device__ __forceinline__ void fin_row(const PeakArgs& pa, const FinArgs& fa, i
 //   kColsFourStep  last pass of the four-step chirp convolution with register rows (conv_kernels.h k_colsreg_inv): a lane holds the
 //                  P1 = M1 points of one column of the 2^P2-column workspace, sample m = r 2^P2 + c, the last row is partial
 //                  (m < n); the wavefronts are NW neighbouring strips
+#if defined(PAL_ABL_FIN) && PAL_ABL_FIN == 9
+#define FIN_SYNC() ((void)0)                                    // timing experiment: no block barriers after the transform (invalid results)
+#else
+#define FIN_SYNC() __syncthreads()
+#endif
 enum { kColsDense = 0, kColsRader89 = 1, kColsStrips = 2, kColsFourStep = 3 };
 
 struct FinSrc {
@@ -455,15 +465,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
   const double kp = zero_rows && zero_rows[2 * g] ? 0.0 : 1.0, kq = zero_rows && 2 * g + 1 < rows && zero_rows[2 * g + 1] ? 0.0 : 1.0;
   // four-step: does sample (t, this lane's column) exist?  (the last row of the workspace's grid is partial: m = t N2 + m2 < n)
   auto ok_at = [&](int t) { return !FOUR || t * N2 + m2 < n; };
+  // Rader form: the output index of slot i sits in lane i of one register (loaded once; a scalar load per sample and pass made
+  // every statistics loop a chain of scalar-memory latencies - 140 of them per wavefront)
+  int slot_t = 0;
   if constexpr (R89) {
+    slot_t = tab->tmap[wave][lane < kR89Slots ? lane : 0];
     r89_columns(Y + size_t(g) * N1 * N2 + m2c, N2, wave, lane, tab, lds_big, ro, c0);
     if (want_median) {                                         // (the exchange plane is free now: it becomes the histograms)
       unsigned* hz = &hist[0][0];
       for (int q = tid; q < 2 * (kLogBins + 1); q += LANES) hz[q] = 0;
     }
-    c0.x *= kp; c0.y *= kq;
+    if (kp == 0.0 || kq == 0.0) {                              // (uniform; a silent microphone's rows are exact zeros)
+      c0.x *= kp; c0.y *= kq;
 #pragma unroll
-    for (int i = 0; i < kR89Slots; ++i) { ro[i].x *= kp; ro[i].y *= kq; }
+      for (int i = 0; i < kR89Slots; ++i) { ro[i].x *= kp; ro[i].y *= kq; }
+    }
   } else if constexpr (FOUR) {
     // conv_kernels.h k_colsreg_inv: the column's M1 points, four-step twiddle, inverse M1-point DFT, then the chirp (bluestein.hip CorrStorer)
     const cd* in = Y + (size_t(g) * P1 << P2) + m2c;
@@ -487,6 +503,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
     }
   }
   stamp();                                                     // 1: accumulated
+  if constexpr (R89 && !HIST) {
+    // every wavefront on its own from here (pfa_fin_lean.h); the transform's last block then finishes both rows
+    if (!fin_lean_r89(ro, c0, slot_t, wave, lane, g, cb, nblk, N2, rows, c_lo, m2, own, inner, pa, fa, stamp)) return;
+    stamp();                                                   // 5
+    if (wave != 0) return;                                     // ONE wavefront finishes the transform's rows (fin_row_wave)
+    bool late = false;
+    for (int q = lane; q < nblk * 4; q += 64) {
+      int spins = 0;
+      while (ld_agent(fa.done + size_t(g) * nblk * 4 + q) != fa.epoch) {
+        if (++spins > kSpinLimit) { late = true; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    if (__ballot(late)) {                                      // the siblings' results are not there: both rows go through the stored-row path
+      if (lane < 2 && 2 * g + lane < rows) { fa.need[2 * g + lane] = 1; atomicAdd(fa.status + 4, 1); atomicAdd(fa.status + 13, 1); }
+      return;
+    }
+#pragma nounroll
+    for (int r = 0; r < 2; ++r)
+      if (2 * g + r < rows) fin_row_wave(pa, fa, 2 * g + r, N1, N2, lane);
+    stamp();                                                   // 6: both rows finished (last block only)
+    return;
+  }
+#if defined(PAL_ABL_FIN) && PAL_ABL_FIN == 1
+  { double acc = c0.x + c0.y; for (int i = 0; i < int(sizeof(ro) / sizeof(ro[0])); ++i) acc += ro[i].x * ro[i].y; if (acc == 1.2345e300) fa.status[3] = 1; return; }
+#endif
   // the samples of this lane, fn(value, t, exists): `value()` yields the sample (formed by two additions in the dense form, so
   // only where it is wanted); t and `exists` are wave-uniform.  Dense form: lag order (t = 0 for chunk 0 only, the chunk
   // ascending, the mirrors descending); Rader form: table order
@@ -495,10 +537,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
 #pragma unroll
       for (int i = 0; i < P1; ++i) fn([&]() { return r ? ro[i].y : ro[i].x; }, i, i * N2 < n);
     } else if constexpr (R89) {
-      const auto* tm = reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(&tab->tmap[wave][0]));
       fn([&]() { return r ? c0.y : c0.x; }, 0, wave == 0);
 #pragma unroll
-      for (int i = 0; i < kR89Slots; ++i) fn([&]() { return r ? ro[i].y : ro[i].x; }, tm[i], true);
+      for (int i = 0; i < kR89Slots; ++i) fn([&]() { return r ? ro[i].y : ro[i].x; }, __builtin_amdgcn_readlane(slot_t, i), true);
     } else {
       const double base = r ? y0.y : y0.x;
       fn([&]() { return base + (r ? sumy : sumx); }, 0, ch == 0);
@@ -514,7 +555,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
       }
     }
   };
-  __syncthreads();
+  FIN_SYNC();
 
   // ---- pass A: histogram of |x| (exact counts), maximum with its first index, minimum, sums
   const int nrow = 2 * g + 1 < rows ? 2 : 1;
@@ -532,7 +573,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
         const double xv = value();
         const bool ok = ok_at(t);                              // (four-step: the last grid row is partial)
         const double x = ok ? xv : 0.0;
-        const bool up = ok && (x > vm || (R89 && x == vm && t < tm));  // (Rader form: not in lag order - the smaller index of equal samples)
+        const bool up = ok & ((x > vm) | (R89 & (x == vm) & (t < tm)));  // (Rader form: not in lag order - the smaller index of equal samples; no short cuts: one basic block)
         vm = up ? x : vm;
         tm = up ? t : tm;
         vn = ok ? min_raw(vn, x) : vn;
@@ -548,11 +589,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
     }
     int im = own && vm > -INFINITY ? m2 + N2 * tm : -1;
     if (!own) { vm = -INFINITY; vn = INFINITY; s1 = s2 = a1 = 0; }
+#if defined(PAL_ABL_FIN) && PAL_ABL_FIN == 21
+    if (vm + vn + s1 + s2 + a1 == 1.2345e300 && im == 77) fa.status[3] = 1;
+    if (r == 1) return;
+    continue;
+#endif
     wave_arg63(vm, im, [](double v1, int i1, double v2, int i2) { return arg_better<0>(v1, i1, v2, i2); });
     vn = wave_min63(vn);
     s1 = wave_sum63(s1);
     s2 = wave_sum63(s2);
     a1 = wave_sum63(a1);
+#if defined(PAL_ABL_FIN) && PAL_ABL_FIN == 22
+    if (vm + vn + s1 + s2 + a1 == 1.2345e300 && im == 77) fa.status[3] = 1;
+    if (r == 1) return;
+    continue;
+#endif
     if (lane == 63) {
       wmax[wave][r] = im >= 0 ? vm : -INFINITY;
       FinPartial& w = res[wave][r];
@@ -563,7 +614,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
         st_agent16(fa.emax + ((size_t(2 * g + r) * pa.splits + cb) * 4 + wave) * 2, vm, double(fa.epoch) * kEpochUnit + double(im + 1));
     }
   }
-  __syncthreads();
+  FIN_SYNC();
   // ---- the block's median bin per row, then the window around it is published
   if (want_median) {
     constexpr int PER = kLogBins / LANES;
@@ -628,6 +679,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
     }
   }
   stamp();                                                     // 2: pass A, histogram windows, edge columns
+#if defined(PAL_ABL_FIN) && PAL_ABL_FIN == 2
+  return;
+#endif
 
   // ---- pass B: the highest strict peak behind the block's exact bound; a block whose bounded search found no peak
   //      searches all its samples (second round), so its result is exact
@@ -704,7 +758,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
         }
       }
     }
-    __syncthreads();
+    FIN_SYNC();
     if (round == 1) break;
     bool again = false;
 #pragma unroll
@@ -715,12 +769,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
       again = again || redo[r];
     }
     if (!again) break;                                         // (uniform: every lane read the same LDS words)
-    __syncthreads();
+    FIN_SYNC();
   }
   // ---- phase 2: the siblings' maxima (published long ago), then the SNR window sums of this block's samples
   stamp();                                                     // 3: pass B
+#if defined(PAL_ABL_FIN) && PAL_ABL_FIN == 3
+  return;
+#endif
   if (tid == 0) s_flag = 0;                                    // (1: a wavefront gave up waiting for the siblings' maxima)
-  __syncthreads();
+  FIN_SYNC();
   if (wave < 2 && 2 * g + wave < rows) {
     const int row = 2 * g + wave;
     double bv = 0;
@@ -746,7 +803,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
     wave_arg63(bv, bi, [](double v1, int i1, double v2, int i2) { return arg_better<0>(v1, i1, v2, i2); });
     if (lane == 63) s_imax[wave] = bi;
   }
-  __syncthreads();
+  FIN_SYNC();
   stamp();                                                     // 4: the row's argmax is known
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -771,7 +828,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
     w2 = wave_sum63(w2);
     if (lane == 63) { res[wave][r].w1 = w1; res[wave][r].w2 = w2; }
   }
-  __syncthreads();
+  FIN_SYNC();
   // ---- publish: lanes 0 / 1 merge the wavefronts of row p / q; then the block is done
   if (tid < 2 && 2 * g + tid < rows) {
     const int r = tid, row = 2 * g + r;
@@ -796,7 +853,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
     st_words(fa.parts + size_t(row) * pa.splits + cb, pt);
   }
   stores_done();                                               // this wavefront's stores (results, histogram windows, edge columns) have landed ...
-  __syncthreads();                                             // ... and so have the other wavefronts' before lane 0 announces the block
+  FIN_SYNC();                                             // ... and so have the other wavefronts' before lane 0 announces the block
   if (tid == 0) st_agent(fa.done + size_t(g) * nblk + cb, fa.epoch);
   stamp();                                                     // 5: published
   if (cb != nblk - 1) return;                                  // (uniform)

@@ -25,6 +25,15 @@ template <class OP> __device__ __forceinline__ double wave_reduce_d(double v, do
   v = op(v, dpp_d<kBcast31, 0xc>(id, v));
   return v;
 }
+template <class OP> __device__ __forceinline__ int wave_reduce_i(int v, int id, OP op) {
+  v = op(v, dpp_i<kShr1>(id, v));
+  v = op(v, dpp_i<kShr2>(id, v));
+  v = op(v, dpp_i<kShr4>(id, v));
+  v = op(v, dpp_i<kShr8>(id, v));
+  v = op(v, dpp_i<kBcast15, 0xa>(id, v));
+  v = op(v, dpp_i<kBcast31, 0xc>(id, v));
+  return v;
+}
 __device__ __forceinline__ double wave_sum63(double v) { return wave_reduce_d(v, 0.0, [](double a, double b) { return a + b; }); }
 __device__ __forceinline__ double wave_max63(double v) { return wave_reduce_d(v, -__builtin_huge_val(), [](double a, double b) { return fmax(a, b); }); }
 __device__ __forceinline__ double wave_min63(double v) { return wave_reduce_d(v, __builtin_huge_val(), [](double a, double b) { return fmin(a, b); }); }
