@@ -253,6 +253,11 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd
     }
   }
 
+  // ---- the lanes' sums and minima, once: rows 2 g and 2 g + 1 share a butterfly (even lanes end with row 2 g's total, odd
+  //      lanes with the other row's).  They stand HERE so that the siblings' maxima have more time to arrive
+  const double rmin = wave_pair_min(vn[0], vn[1]);
+  const double r1 = wave_pair_sum(s1[0], s1[1]), r2 = wave_pair_sum(s2[0], s2[1]), ra = wave_pair_sum(a1[0], a1[1]);
+
   // ---- the row's argmax from the siblings' maxima (published long ago), then the SNR window sums of this wavefront's samples
   double w1[2] = {0, 0}, w2[2] = {0, 0};
   bool gave_up = false;
@@ -302,15 +307,12 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd
   if (gave_up && lane == 0) atomicAdd(fa.status + 13, 1);
   stamp();                                                     // 3: the row's argmax, window sums
 #if defined(PAL_ABL_LEAN) && PAL_ABL_LEAN < 5
-  if (vn[0] + s1[0] + s2[0] + a1[0] + vn[1] + s1[1] + s2[1] + a1[1] + pt[0].hb + pt[1].hb + pt[0].hw + pt[1].hw + w1[0] + w2[0] + w1[1] + w2[1] == 1.2345e300) fa.status[3] = 1;
+  if (rmin + r1 + r2 + ra + pt[0].hb + pt[1].hb + pt[0].hw + pt[1].hw + w1[0] + w2[0] + w1[1] + w2[1] == 1.2345e300) fa.status[3] = 1;
   return false;
 #endif
 
-  // ---- the lanes' sums and minima, once: rows 2 g and 2 g + 1 share a butterfly (even lanes end with row 2 g's total, odd
-  //      lanes with the other row's); lane r publishes row r's results, then the wavefront's `done` word follows
+  // ---- the window sums' butterfly; lane r publishes row r's results, then the wavefront's `done` word follows
   {
-    const double rmin = wave_pair_min(vn[0], vn[1]);
-    const double r1 = wave_pair_sum(s1[0], s1[1]), r2 = wave_pair_sum(s2[0], s2[1]), ra = wave_pair_sum(a1[0], a1[1]);
     double q1 = 0, q2 = 0;
     if (have_w[0] || have_w[1]) { q1 = wave_pair_sum(w1[0], w1[1]); q2 = wave_pair_sum(w2[0], w2[1]); }   // (uniform)
     if (lane < nrow) {
