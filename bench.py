@@ -421,11 +421,15 @@ def main() -> None:
     if dom_launches:
         live_s = dom_ms * 1e-3 / dom_launches
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        # counter passes are kept per configuration (tools/profile_round.sh): profiles/pmc_traffic.json for the metric run,
+        # profiles/pmc_traffic_<config>.json for C2 ... C5; a workload given by --mics / --length has none
+        tname = "pmc_traffic.json" if args.config == "metric" else f"pmc_traffic_{args.config}.json"
+        tpath = os.path.join(ROOT, "profiles", tname)
+        default_shape = not args.mics and not args.length
+        if os.path.exists(tpath) and default_shape:
             try:
                 traffic = json.load(open(tpath)).get(dom_name)
-                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command, NOT this run)"
+                traffic_src = f"profiles/{tname} (rocprofv3 --pmc passes of an earlier run of this command, NOT this run)"
             except Exception:
                 traffic = None
         kb = own(dom_name)

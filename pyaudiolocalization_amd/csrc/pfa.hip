@@ -379,10 +379,14 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
 bool Engine::pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const {
   const Pfa& f = pl.pfa;
   static const bool strips = getenv("PAL_FIN_STRIPS") != nullptr;
-  static const bool dense = getenv("PAL_FIN_DENSE") != nullptr;
-  // Measured over L = 44100 ... 44299 (profiles/r03_c_length_sweep_fin*.csv): the pass wins where the columns are the Rader-89
-  // transform (+2 ... +9 %), and loses 30 - 40 % with the dense column DFT of 25 <= n1 <= 85 (opt-in: PAL_FIN_DENSE=1)
-  const bool cols_ok = f.r89 != nullptr || (dense && f.nch >= 2) || strips;
+  static const char* dense_env = getenv("PAL_FIN_DENSE");     // 1 / 0: the pass on every / no dense column DFT (default: by measurement)
+  // Measured over L = 44100 ... 44299 with the per-wavefront statistics of pfa_fin_lean.h (profiles/r03_c_length_sweep_dense_fin.csv
+  // against ..._default.csv): the pass wins with Rader-89 columns (+10 %), with two or four chunks of output indices (+3 ... +12 %, +4 %)
+  // and with short columns beside row tiles of up to 8192 points (+8 %); three chunks leave the fourth wavefront idle (-2 %), and
+  // beside the 16384-point row tiles it is a wash
+  bool cols_ok = f.r89 != nullptr || f.nch == 2 || f.nch == 4 || (f.nch <= 1 && f.lm <= 13);
+  if (dense_env) cols_ok = f.r89 != nullptr || atoi(dense_env) != 0;
+  if (f.nch <= 1 && strips) cols_ok = true;
   return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.n2 >= 256 && cols_ok;
 }
 
@@ -525,8 +529,9 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
     FinSrc src{Y, f.T, static_cast<const Rader89Tab*>(f.r89), nullptr, nullptr, nullptr};
     PAL_TRY(fin_serialize(on));
 #define PAL_COLS_FIN(MODE, HI, FU, NW) k_pfa_cols_fin<MODE, kPfaTC, kPfaUnr, HI, FU, NW><<<grid, dim3(64 * NW), 0, on>>>(src, f.n1, f.n2, G, f.nch, nblk, zero_rows, a, fa, rows)
+    if (!hist) fa.pw = shortcols ? 4 : nw;                    // one FinPartial / `done` word per wavefront (pfa_fin_lean.h)
     if (shortcols) { if (hist) PAL_COLS_FIN(kColsStrips, true, false, 4); else PAL_COLS_FIN(kColsStrips, false, false, 4); }
-    else if (f.r89 && full && nw == 4) { if (hist) PAL_COLS_FIN(kColsRader89, true, true, 4); else { fa.pw = 4; PAL_COLS_FIN(kColsRader89, false, true, 4); } }
+    else if (f.r89 && full && nw == 4) { if (hist) PAL_COLS_FIN(kColsRader89, true, true, 4); else PAL_COLS_FIN(kColsRader89, false, true, 4); }
     else if (nw == 2) {
       if (hist) { if (full) PAL_COLS_FIN(kColsDense, true, true, 2); else PAL_COLS_FIN(kColsDense, true, false, 2); }
       else { if (full) PAL_COLS_FIN(kColsDense, false, true, 2); else PAL_COLS_FIN(kColsDense, false, false, 2); }

@@ -405,7 +405,7 @@ struct FinSrc {
 // HIST: threshold method 'median' with a histogram window per block (a rigorous 0.5 % interval for the row's median); false:
 //       'adaptive', or 'median' bounded without histograms (FinArgs.cheb: multipliers up to 2)
 template <int MODE, int P1, int P2, bool HIST, bool FULL, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE == kColsFourStep && (P1 > 16) ? 2 : 3))) void k_pfa_cols_fin(FinSrc src, int N1, int N2, int G, int nch, int nblk,
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE == kColsRader89 || (MODE == kColsFourStep && P1 <= 16) ? 3 : 2))) void k_pfa_cols_fin(FinSrc src, int N1, int N2, int G, int nch, int nblk,
                                                       const int* __restrict__ zero_rows, PeakArgs pa, FinArgs fa, int rows) {
   constexpr bool R89 = MODE == kColsRader89, FOUR = MODE == kColsFourStep;
   constexpr bool STRIPS = MODE == kColsStrips || MODE == kColsFourStep;
@@ -503,15 +503,35 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
     }
   }
   stamp();                                                     // 1: accumulated
-  if constexpr (R89 && !HIST) {
-    // every wavefront on its own from here (pfa_fin_lean.h); the transform's last block then finishes both rows
-    if (!fin_lean_r89(ro, c0, slot_t, wave, lane, g, cb, nblk, N2, rows, c_lo, m2, own, inner, pa, fa, stamp)) return;
+  if constexpr (!HIST && !FOUR) {
+    // every wavefront on its own from here (pfa_fin_lean.h); ONE wavefront of the transform's last block then finishes both rows
+    bool last;
+    if constexpr (R89) {
+      last = fin_lean_r89<true>(ro, c0, slot_t, 0u, wave, lane, g, cb, nblk, N1, N2, rows, c_lo, m2, own, inner, cb == 0 || cb == nblk - 1, pa, fa, stamp);
+    } else {
+      // dense column DFT: the accumulators become samples once (slot 1 + tt: t = ch TC + tt + 1, slot 1 + TC + tt: N1 - t; slot 0: t = 0)
+      static_assert(R89 || 2 * TCD == kR89Slots, "22 slots per wavefront");
+      cd zs[kR89Slots];
+      const cd z0 = mk(y0.x + sumx, y0.y + sumy);
+      unsigned emask = active && ch == 0 ? 1u : 0u;
+#pragma unroll
+      for (int tt = 0; tt < TCD; ++tt) {
+        zs[tt] = mk(y0.x + cx[tt] - sy[tt], y0.y + cy[tt] + sx[tt]);
+        zs[TCD + tt] = mk(y0.x + cx[tt] + sy[tt], y0.y + cy[tt] - sx[tt]);
+        if (active && (FULL || ch * TC + tt + 1 <= h)) emask |= (1u << (1 + tt)) | (1u << (1 + TCD + tt));
+      }
+      const int tl = ch * TC + (lane < TCD ? lane : lane - TCD) + 1;
+      const int st = lane < TCD ? tl : N1 - tl;
+      last = fin_lean_r89<false>(zs, z0, st, emask, wave, lane, g, cb, nblk, N1, N2, rows, c_lo, m2, own, inner,
+                                 active && (c_lo == 0 || c_hi == N2), pa, fa, stamp);
+    }
+    if (!last) return;
     stamp();                                                   // 5
     if (wave != 0) return;                                     // ONE wavefront finishes the transform's rows (fin_row_wave)
     bool late = false;
-    for (int q = lane; q < nblk * 4; q += 64) {
+    for (int q = lane; q < nblk * fa.pw; q += 64) {
       int spins = 0;
-      while (ld_agent(fa.done + size_t(g) * nblk * 4 + q) != fa.epoch) {
+      while (ld_agent(fa.done + size_t(g) * nblk * fa.pw + q) != fa.epoch) {
         if (++spins > kSpinLimit) { late = true; break; }
         __builtin_amdgcn_s_sleep(8);
       }

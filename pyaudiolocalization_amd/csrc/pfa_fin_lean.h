@@ -109,23 +109,28 @@ __device__ __forceinline__ double wave_pair_min(double a, double b) { return wav
 
 // One wavefront of a Rader-89 column block: ro[i] = c[t] of slot i + 1 (t = lane i of slot_t), c0 = c[0] (slot 0, wavefront 0
 // only); real parts = row 2 g, imaginary parts = row 2 g + 1.  Returns true in the transform's last block (it finishes the rows).
-template <class STAMP>
-__device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd c0, const int slot_t, const int wave, const int lane,
-                                             const int g, const int cb, const int nblk, const int N2, const int rows, const int c_lo,
-                                             const int m2, const bool own, const bool inner, const PeakArgs& pa, const FinArgs& fa, STAMP&& stamp) {
-  const int n = pa.n, S = pa.splits;
+// General form (dense column DFTs, strips): `emask` bit s = slot s exists (slot 0 = c0; ALL: every slot 1 .. 22 exists and slot 0 in
+// wavefront 0 only - the Rader-89 case); `edge_block`: the wavefront's columns touch the grid's first or last column; the
+// wavefront's entries sit at index (cb, wave) of fa.pw per block.
+template <bool ALL, class STAMP>
+__device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd c0, const int slot_t, const unsigned emask, const int wave, const int lane,
+                                             const int g, const int cb, const int nblk, const int N1, const int N2, const int rows, const int c_lo,
+                                             const int m2, const bool own, const bool inner, const bool edge_block, const PeakArgs& pa, const FinArgs& fa, STAMP&& stamp) {
+  const int n = pa.n, S = pa.splits, PW = fa.pw;
   const unsigned long long ownm = __ballot(own), innerm = __ballot(inner);
   const int nrow = 2 * g + 1 < rows ? 2 : 1;
   const bool windowed = fa.windowed != 0;
   auto T = [&](int slot) { return slot == 0 ? 0 : __builtin_amdgcn_readlane(slot_t, slot - 1); };
   auto for_slots = [&](int r, auto&& fn) {                     // fn(sample, slot): slot is a constant once unrolled
-    if (wave == 0) fn(r ? c0.y : c0.x, 0);
+    if (ALL ? wave == 0 : (emask & 1u) != 0) fn(r ? c0.y : c0.x, 0);
 #pragma unroll
-    for (int i = 0; i < kR89Slots; ++i) fn(r ? ro[i].y : ro[i].x, i + 1);
+    for (int i = 0; i < kR89Slots; ++i)
+      if (ALL || (emask >> (i + 1) & 1u)) fn(r ? ro[i].y : ro[i].x, i + 1);   // (uniform)
   };
   auto slot_mask = [&](int t_lo, int t_hi) -> unsigned {       // slots whose output index lies in [t_lo, t_hi]
     const unsigned long long b = __ballot(lane < kR89Slots && slot_t >= t_lo && slot_t <= t_hi);
-    return (unsigned(b) << 1) | (wave == 0 && t_lo <= 0 && t_hi >= 0 ? 1u : 0u);
+    const unsigned m = (unsigned(b) << 1) | (t_lo <= 0 && t_hi >= 0 ? 1u : 0u);
+    return ALL ? (wave == 0 ? m : m & ~1u) : m & emask;
   };
   // the lag window and its margins of distance - 1 samples (the row's end points are never peaks)
   int lo1 = 1, hi1 = 0;
@@ -174,7 +179,7 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd
     if (im == INT_MAX) im = -1;
     // the wavefront's maximum and the first index of it go out NOW, in one 16-byte store that nobody waits for
     if (lane == 0)
-      st_agent16(fa.emax + ((size_t(2 * g + r) * S + cb) * 4 + wave) * 2, im >= 0 ? V : -INFINITY, double(fa.epoch) * kEpochUnit + double(im + 1));
+      st_agent16(fa.emax + ((size_t(2 * g + r) * S + cb) * PW + wave) * 2, im >= 0 ? V : -INFINITY, double(fa.epoch) * kEpochUnit + double(im + 1));
 
     // ---- pass B: the highest strict peak.  The maximum itself, if it is one (and single: equal samples are told apart by the
     //      search); else the samples at or above 0.8 V, else all of them - exact each time
@@ -238,14 +243,14 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd
 #endif
 
   // ---- the grid's edge columns go to the finishing block as they are (blocks 0 and nblk - 1 only)
-  if (cb == 0 || cb == nblk - 1) {                             // (uniform)
+  if (edge_block) {                                            // (uniform)
     const bool mine = own && (m2 <= 1 || m2 >= N2 - 2);
     if (__ballot(mine)) {
       const int e = m2 <= 1 ? m2 : 3 - (N2 - 1 - m2);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         if (r >= nrow) continue;
-        double* dst = fa.edge + (size_t(2 * g + r) * 4 + (mine ? e : 0)) * kR89;
+        double* dst = fa.edge + (size_t(2 * g + r) * 4 + (mine ? e : 0)) * N1;
         for_slots(r, [&](double x, int slot) {
           if (mine) st_agent(dst + T(slot), x);
         });
@@ -268,10 +273,10 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd
     const int row = 2 * g + r;
     double bv = -INFINITY;
     int bi = -1;
-    const double* em = fa.emax + size_t(row) * S * 8;
+    const double* em = fa.emax + size_t(row) * S * PW * 2;
     const double want = double(fa.epoch);
     bool late = false;
-    for (int q = lane; q < S * 4; q += 64) {
+    for (int q = lane; q < S * PW; q += 64) {
       double v = 0, code = 0;
       int spins = 0;
       for (;;) {                                               // (the entry of this launch: its second word carries the launch number)
@@ -323,13 +328,13 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd
       o.mb = second ? pt[1].mb : pt[0].mb; o.mw = second ? pt[1].mw : pt[0].mw; o.mm = second ? pt[1].mm : pt[0].mm;
       o.vmin = rmin; o.s1 = r1; o.s2 = r2; o.a1 = ra; o.w1 = q1; o.w2 = q2;
       o.pad = gave_up ? 1 : 0;
-      st_words(fa.parts + (size_t(2 * g + lane) * S + cb) * 4 + wave, o);
+      st_words(fa.parts + (size_t(2 * g + lane) * S + cb) * PW + wave, o);
     }
   }
 #if !defined(PAL_ABL_LEAN) || PAL_ABL_LEAN != 6
   stores_done();                                               // this wavefront's stores (results, edge columns) have landed
 #endif
-  if (lane == 0) st_agent(fa.done + (size_t(g) * nblk + cb) * 4 + wave, fa.epoch);
+  if (lane == 0) st_agent(fa.done + (size_t(g) * nblk + cb) * PW + wave, fa.epoch);
   stamp();                                                     // 4: published
   return cb == nblk - 1;
 }
@@ -338,7 +343,7 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd
 // ---- the finishing WAVEFRONT: one row from the wavefronts' published results (64 lanes, uniform control flow; the counterpart of
 //      pfa_cols_fin.h fin_row for FinArgs.pw = 4 and no histograms - same rules, same order of the tests) ----
 __device__ __forceinline__ void fin_row_wave(const PeakArgs& pa, const FinArgs& fa, int row, int N1, int N2, int lane) {
-  const int S = pa.splits, n = pa.n, P = S * 4;
+  const int S = pa.splits, n = pa.n, P = S * fa.pw;
   const bool windowed = fa.windowed != 0;
   const bool want_median = pa.method == 0;
   double vmax = 0, vmin = INFINITY, hb = 0, plat = -INFINITY, s1 = 0, s2 = 0, a1 = 0, w1 = 0, w2 = 0;
@@ -347,7 +352,7 @@ __device__ __forceinline__ void fin_row_wave(const PeakArgs& pa, const FinArgs& 
   int mw = -1, mm = -1;
   bool abandoned = false;
   {
-    const double* em = fa.emax + size_t(row) * S * 8;
+    const double* em = fa.emax + size_t(row) * P * 2;
     for (int q = lane; q < P; q += 64) {
       const double v = ld_agent(em + 2 * q);
       const int i = int(ld_agent(em + 2 * q + 1) - double(fa.epoch) * kEpochUnit) - 1;      // (complete: every wavefront of the transform is done)

@@ -285,7 +285,10 @@ __device__ __forceinline__ void pfa_cols_accumulate(const cd* __restrict__ Yg, i
 #pragma unroll
   for (int tt = 0; tt < TC; ++tt) cx[tt] = sy[tt] = cy[tt] = sx[tt] = 0.0;
   sumx = sumy = 0.0;
-  const double* Tj = T + size_t(ch) * 2 * TC;
+  // (constant address space: wave-uniform entries of a table nobody writes -> scalar loads.  A kernel argument marked __restrict__
+  //  gets them anyway; a pointer that arrives inside a struct - pfa_cols_fin.h's FinSrc - did not, and the dense finishing pass
+  //  ran on vector loads with a wait behind each: 640 us against 270)
+  const auto* Tj = reinterpret_cast<const __attribute__((address_space(4))) double*>(reinterpret_cast<uintptr_t>(T)) + size_t(ch) * 2 * TC;
   const size_t tstep = size_t(nch) * 2 * TC;
   y0 = Yg[0];
   cd yj[UNR], ym[UNR];

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the finishing column pass (PAL_FIN=1, pfa_cols_fin.h) against the stored-row path (PAL_FIN=0) on one box:
 every record field of random and structured frames, both window modes, both threshold methods.
-    python tools/check_fin.py [mics] [frames]"""
+    python tools/check_fin.py [mics] [frames] [length=44100]     (PAL_FIN_DENSE=1 / PAL_FIN_STRIPS=1: the pass on dense column DFTs)"""
 import os
 import sys
 
@@ -20,13 +20,14 @@ def engine(fin):
 def main():
     mics = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     nfr = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    L = int(sys.argv[3]) if len(sys.argv) > 3 else 44100
     from pyaudiolocalization_amd.synthetic import metric_frames
     a, b = engine(True), engine(False)
     rng = np.random.default_rng(5)
-    cases = {"metric": metric_frames(nfr, mics, 44100),
-             "noise": rng.standard_normal((nfr, mics, 44100)),
-             "tone+noise": np.sin(0.05 * np.arange(44100))[None, None, :] + 0.3 * rng.standard_normal((nfr, mics, 44100))}
-    z = rng.standard_normal((1, mics, 44100)); z[0, 1] = 0.0
+    cases = {"metric": metric_frames(nfr, mics, L),
+             "noise": rng.standard_normal((nfr, mics, L)),
+             "tone+noise": np.sin(0.05 * np.arange(L))[None, None, :] + 0.3 * rng.standard_normal((nfr, mics, L))}
+    z = rng.standard_normal((1, mics, L)); z[0, 1] = 0.0
     cases["silent mic"] = z
     bad = 0
     for name, fr in cases.items():

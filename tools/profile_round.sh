@@ -23,6 +23,13 @@ python3 $ROOT/tools/pmc_summary.py $OUT/pmc $OUT/pmc_traffic.json > $OUT/pmc_sum
 for cfg in c2 c3 c4 c5; do
   python3 $ROOT/bench.py --config $cfg --steps 10 --warmup 3 > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; echo "bench $cfg rc=$?"
   rocprofv3 --kernel-trace --stats -d $OUT/stats_$cfg -o stats --output-format csv -- python3 $ROOT/bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline > $OUT/stats_$cfg.log 2>&1
+  # memory-side traffic and fp64 operations of the configuration's kernels: the same three counter passes as the metric run
+  CFG_CMD="python3 $ROOT/bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events"
+  for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "flops SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVES"; do
+    set -- $pass; name=$1; shift
+    timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$cfg/$name -o $name --output-format csv -- $CFG_CMD > $OUT/pmc_${cfg}_$name.log 2>&1 || echo "pass $cfg $name failed"
+  done
+  python3 $ROOT/tools/pmc_summary.py $OUT/pmc_$cfg $OUT/pmc_traffic_$cfg.json > $OUT/pmc_summary_$cfg.txt 2>&1
 done
 python3 $ROOT/tools/bench_stream.py 128 2 > $OUT/stream.json 2> $OUT/stream.err; echo "stream rc=$?"
 find $OUT -name "*.db" -delete

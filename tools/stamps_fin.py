@@ -9,12 +9,13 @@ import numpy as np
 from pyaudiolocalization_amd import Engine, make_params, RECORD
 from pyaudiolocalization_amd.synthetic import metric_frames
 m = 32
-fr = metric_frames(1, m, 44100)
+L = int(os.environ.get("STAMPS_L", "44100"))
+fr = metric_frames(1, m, L)
 e = Engine(0)
 d = e.alloc(fr.nbytes); e.upload(d, fr)
 t = e.alloc(m * (m - 1) // 2 * RECORD.itemsize)
 prm = make_params(44100.0, 1, "median", 1.0, 0.05)
 for _ in range(3):
-    e.gcc_phat_all_pairs_dev(d, 1, m, 44100, prm, t); e.synchronize()
+    e.gcc_phat_all_pairs_dev(d, 1, m, L, prm, t); e.synchronize()
     print("----", file=sys.stderr)
 e.close()
