@@ -384,7 +384,7 @@ bool Engine::pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const {
   // against ..._default.csv): the pass wins with Rader-89 columns (+10 %), with two or four chunks of output indices (+3 ... +12 %, +4 %)
   // and with short columns beside row tiles of up to 8192 points (+8 %); three chunks leave the fourth wavefront idle (-2 %), and
   // beside the 16384-point row tiles it is a wash
-  bool cols_ok = f.r89 != nullptr || f.nch == 2 || f.nch == 4 || (f.nch <= 1 && f.lm <= 13);
+  bool cols_ok = f.r89 != nullptr || (f.nch >= 2 && f.nch <= 4) || (f.nch <= 1 && f.lm <= 13);
   if (dense_env) cols_ok = f.r89 != nullptr || atoi(dense_env) != 0;
   if (f.nch <= 1 && strips) cols_ok = true;
   return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.n2 >= 256 && cols_ok;
@@ -525,7 +525,7 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
     const bool full = (f.n1 - 1) / 2 == f.nch * kPfaTC;
     // histograms only where the bound sqrt(2 mean(x^2)) on the median cannot decide: multipliers above 2 (or negative)
     const bool hist = !(a.method > 0 || fa.cheb);
-    const int nw = f.nch == 2 ? 2 : 4;
+    const int nw = f.nch == 2 ? 2 : (f.nch == 3 && !hist ? 3 : 4);   // (three chunks: three wavefronts where the statistics are per wavefront)
     FinSrc src{Y, f.T, static_cast<const Rader89Tab*>(f.r89), nullptr, nullptr, nullptr};
     PAL_TRY(fin_serialize(on));
 #define PAL_COLS_FIN(MODE, HI, FU, NW) k_pfa_cols_fin<MODE, kPfaTC, kPfaUnr, HI, FU, NW><<<grid, dim3(64 * NW), 0, on>>>(src, f.n1, f.n2, G, f.nch, nblk, zero_rows, a, fa, rows)
@@ -535,6 +535,8 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
     else if (nw == 2) {
       if (hist) { if (full) PAL_COLS_FIN(kColsDense, true, true, 2); else PAL_COLS_FIN(kColsDense, true, false, 2); }
       else { if (full) PAL_COLS_FIN(kColsDense, false, true, 2); else PAL_COLS_FIN(kColsDense, false, false, 2); }
+    } else if (nw == 3) {
+      if (full) PAL_COLS_FIN(kColsDense, false, true, 3); else PAL_COLS_FIN(kColsDense, false, false, 3);
     } else {
       if (hist) { if (full) PAL_COLS_FIN(kColsDense, true, true, 4); else PAL_COLS_FIN(kColsDense, true, false, 4); }
       else { if (full) PAL_COLS_FIN(kColsDense, false, true, 4); else PAL_COLS_FIN(kColsDense, false, false, 4); }
