@@ -500,6 +500,7 @@ int Engine::fourstep_pair_group_fin(const Plan& pl, const cd* W, int G, int rows
     snprintf(name, sizeof name, "k_colsreg_fin<%d>", M1);
     ProfScope ps(this, name, on);
     FinSrc src{W, nullptr, nullptr, c.twA, c.twB, pl.w};
+    fa.pw = 4;                                                 // one FinPartial / `done` word per wavefront (pfa_fin_lean.h)
     PAL_TRY(fin_serialize(on));
     PAL_SWITCH_M1(M1, c.l2, k_pfa_cols_fin<kColsFourStep, MM, LR, false, false, 4><<<dim3(nwg), dim3(256), 0, on>>>(src, M1, N2, G, 1, nblk, zero_rows, a, fa, rows));
     PAL_HIP(hipGetLastError());

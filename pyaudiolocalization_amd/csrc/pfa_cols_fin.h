@@ -503,11 +503,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
     }
   }
   stamp();                                                     // 1: accumulated
-  if constexpr (!HIST && !FOUR) {
+  if constexpr (!HIST) {
     // every wavefront on its own from here (pfa_fin_lean.h); ONE wavefront of the transform's last block then finishes both rows
     bool last;
     if constexpr (R89) {
-      last = fin_lean_r89<true>(ro, c0, slot_t, 0u, wave, lane, g, cb, nblk, N1, N2, rows, c_lo, m2, own, inner, cb == 0 || cb == nblk - 1, pa, fa, stamp);
+      last = fin_lean_r89<true, false, kR89Slots>(ro, c0, slot_t, 0u, wave, lane, g, cb, nblk, N1, N2, rows, c_lo, m2, own, inner, cb == 0 || cb == nblk - 1,
+                                                  -1, true, pa, fa, stamp);
+    } else if constexpr (FOUR) {
+      // four-step workspace: slot 1 + r = grid row r (t = r), no slot 0; the row ends inside grid row (n - 1) / N2
+      unsigned emask = 0;
+#pragma unroll
+      for (int r = 0; r < P1; ++r)
+        if (r * N2 < n) emask |= 1u << (1 + r);
+      const int pr = (n - 1) / N2;
+      last = fin_lean_r89<false, true, P1>(ro, mk(0, 0), lane, emask, wave, lane, g, cb, nblk, N1, N2, rows, c_lo, m2, own, inner, c_lo == 0 || c_hi == N2,
+                                           1 + pr, pr * N2 + m2 < n, pa, fa, stamp);
     } else {
       // dense column DFT: the accumulators become samples once (slot 1 + tt: t = ch TC + tt + 1, slot 1 + TC + tt: N1 - t; slot 0: t = 0)
       static_assert(R89 || 2 * TCD == kR89Slots, "22 slots per wavefront");
@@ -522,8 +532,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
       }
       const int tl = ch * TC + (lane < TCD ? lane : lane - TCD) + 1;
       const int st = lane < TCD ? tl : N1 - tl;
-      last = fin_lean_r89<false>(zs, z0, st, emask, wave, lane, g, cb, nblk, N1, N2, rows, c_lo, m2, own, inner,
-                                 active && (c_lo == 0 || c_hi == N2), pa, fa, stamp);
+      last = fin_lean_r89<false, false, kR89Slots>(zs, z0, st, emask, wave, lane, g, cb, nblk, N1, N2, rows, c_lo, m2, own, inner,
+                                                   active && (c_lo == 0 || c_hi == N2), -1, true, pa, fa, stamp);
     }
     if (!last) return;
     stamp();                                                   // 5

@@ -112,11 +112,16 @@ __device__ __forceinline__ double wave_pair_min(double a, double b) { return wav
 // General form (dense column DFTs, strips): `emask` bit s = slot s exists (slot 0 = c0; ALL: every slot 1 .. 22 exists and slot 0 in
 // wavefront 0 only - the Rader-89 case); `edge_block`: the wavefront's columns touch the grid's first or last column; the
 // wavefront's entries sit at index (cb, wave) of fa.pw per block.
-template <bool ALL, class STAMP>
-__device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd c0, const int slot_t, const unsigned emask, const int wave, const int lane,
+// PART (the four-step workspace, sample m = N2 t + m2 < n): the row ends inside slot `pslot` - its samples are valid where `pvalid`
+// (the others hold zeros, which the sums may see but maxima, minima and the index search must not), later slots do not exist.
+template <bool ALL, bool PART, int NS, class STAMP>
+__device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[NS], const cd c0, const int slot_t, const unsigned emask, const int wave, const int lane,
                                              const int g, const int cb, const int nblk, const int N1, const int N2, const int rows, const int c_lo,
-                                             const int m2, const bool own, const bool inner, const bool edge_block, const PeakArgs& pa, const FinArgs& fa, STAMP&& stamp) {
+                                             const int m2, const bool own, const bool inner, const bool edge_block, const int pslot, const bool pvalid,
+                                             const PeakArgs& pa, const FinArgs& fa, STAMP&& stamp) {
+  static_assert(NS + 1 <= 32, "slot masks are 32 bits");
   const int n = pa.n, S = pa.splits, PW = fa.pw;
+  const unsigned long long pvm = PART ? __ballot(pvalid) : ~0ull;
   const unsigned long long ownm = __ballot(own), innerm = __ballot(inner);
   const int nrow = 2 * g + 1 < rows ? 2 : 1;
   const bool windowed = fa.windowed != 0;
@@ -124,11 +129,11 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd
   auto for_slots = [&](int r, auto&& fn) {                     // fn(sample, slot): slot is a constant once unrolled
     if (ALL ? wave == 0 : (emask & 1u) != 0) fn(r ? c0.y : c0.x, 0);
 #pragma unroll
-    for (int i = 0; i < kR89Slots; ++i)
+    for (int i = 0; i < NS; ++i)
       if (ALL || (emask >> (i + 1) & 1u)) fn(r ? ro[i].y : ro[i].x, i + 1);   // (uniform)
   };
   auto slot_mask = [&](int t_lo, int t_hi) -> unsigned {       // slots whose output index lies in [t_lo, t_hi]
-    const unsigned long long b = __ballot(lane < kR89Slots && slot_t >= t_lo && slot_t <= t_hi);
+    const unsigned long long b = __ballot(lane < NS && slot_t >= t_lo && slot_t <= t_hi);
     const unsigned m = (unsigned(b) << 1) | (t_lo <= 0 && t_hi >= 0 ? 1u : 0u);
     return ALL ? (wave == 0 ? m : m & ~1u) : m & emask;
   };
@@ -152,9 +157,14 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd
     if (r >= nrow) continue;                                   // (uniform)
     // ---- pass A
     double vm = -INFINITY, vmin = INFINITY, t1 = 0, t2 = 0, ta = 0;
-    for_slots(r, [&](double x, int) {
-      vm = max_raw(vm, x);
-      vmin = min_raw(vmin, x);
+    for_slots(r, [&](double x, int slot) {
+      if (PART && slot == pslot) {                             // (uniform) the row's last, partial slot
+        vm = pvalid ? max_raw(vm, x) : vm;
+        vmin = pvalid ? min_raw(vmin, x) : vmin;
+      } else {
+        vm = max_raw(vm, x);
+        vmin = min_raw(vmin, x);
+      }
       t1 += x;
       t2 = __builtin_fma(x, x, t2);
       ta += fabs(x);
@@ -167,13 +177,13 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd
     int im = INT_MAX, nhit = 0;
     bool vpeak = false;
     for_slots(r, [&](double x, int slot) {
-      const unsigned long long mk = __ballot(x == V) & ownm;
+      const unsigned long long mk = __ballot(x == V) & ownm & (PART && slot == pslot ? pvm : ~0ull);
       if (mk) {                                                // (uniform)
         const int l = int(__builtin_ctzll(mk));                // (own lanes are 1 .. 62: both neighbour lanes exist)
         const int cand = N2 * T(slot) + (c_lo - 1) + l;
         im = cand < im ? cand : im;
         nhit += __builtin_popcountll(mk);
-        vpeak = (innerm >> l & 1ull) && readlane_d(x, l - 1) < V && readlane_d(x, l + 1) < V;
+        vpeak = (innerm >> l & 1ull) && (!PART || cand <= n - 2) && readlane_d(x, l - 1) < V && readlane_d(x, l + 1) < V;
       }
     });
     if (im == INT_MAX) im = -1;
@@ -197,11 +207,12 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[kR89Slots], const cd
           if (__ballot(x >= myfloor)) {
             const int m = m2 + N2 * T(slot);
             const double left = from_lower_lane(x), right = from_upper_lane(x);
-            const bool cand = inner && x >= pfloor && (x > hb || (x == hb && m > mb));
+            const bool here = inner && (!PART || m <= n - 2);  // (four-step: the row ends inside the grid's last row)
+            const bool cand = here && x >= pfloor && (x > hb || (x == hb && m > mb));
             const bool pk = cand && left < x && right < x;
             hb = pk ? x : hb;
             mb = pk ? m : mb;
-            plat = inner && x >= pfloor && left == x ? fmax(plat, x) : plat;
+            plat = here && x >= pfloor && left == x ? fmax(plat, x) : plat;
           }
         });
         uniform_arg_sparse(hb, mb, [](double v1, int i1, double v2, int i2) { return higher(v1, i1, v2, i2); });
