@@ -182,6 +182,29 @@ def cpu_baseline(frame0: np.ndarray, fs: float, med, cpu_mics: int, budget_s: fl
     return cpu, want, cm
 
 
+def traffic_lookup(table, name):
+    """A kernel's bytes per launch from a tools/pmc_summary.py table.  The profiler's names carry template arguments the
+    engine's labels drop (k_pfa_rows_big<14,32> for k_pfa_rows_big<14>, k_colsreg2_fwd<48,13,PairLoader> for
+    k_colsreg_fwd<48,PairLoader>): both sides are reduced to base name + first number + the loader / storer."""
+    import re
+
+    def norm(k):
+        k = k.replace("colsreg2_", "colsreg_")
+        m = re.match(r"([A-Za-z_0-9]+)(?:<(\d+)((?:,[^>]*)?)>)?", k)
+        if not m:
+            return k
+        words = [w for w in (m.group(3) or "").split(",") if w and not w.isdigit()]
+        return (m.group(1), m.group(2), tuple(words))
+
+    if name in table:
+        return table[name]
+    want = norm(name)
+    for k, v in table.items():
+        if norm(k) == want:
+            return v
+    return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -428,7 +451,7 @@ def main() -> None:
         default_shape = not args.mics and not args.length
         if os.path.exists(tpath) and default_shape:
             try:
-                traffic = json.load(open(tpath)).get(dom_name)
+                traffic = traffic_lookup(json.load(open(tpath)), dom_name)
                 traffic_src = f"profiles/{tname} (rocprofv3 --pmc passes of an earlier run of this command, NOT this run)"
             except Exception:
                 traffic = None

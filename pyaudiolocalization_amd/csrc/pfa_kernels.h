@@ -373,17 +373,5 @@ __global__ __launch_bounds__(256) void k_pfa_cols(const cd* __restrict__ Y, doub
   pfa_cols_block<TC, UNR>(Y, corr, stride, N1, N2, nch, T, zero_rows, int(blockIdx.x % G), int(blockIdx.x / G), ch);
 }
 
-// the same for a LIST of transforms (the rows the finishing column pass flagged, pfa_cols_fin.h): the grid is a fraction of the
-// launch group's and walks the list; an empty list costs a handful of workgroups that leave at once
-template <int TC, int UNR>
-__global__ __launch_bounds__(256) void k_pfa_cols_list(const cd* __restrict__ Y, double* __restrict__ corr, size_t stride,
-                                                       int N1, int N2, int nb64, int nch, const double* __restrict__ T,
-                                                       const int* __restrict__ zero_rows, const int* __restrict__ list,
-                                                       const int* __restrict__ count) {
-  const int ch = int(blockIdx.y) * 4 + __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
-  if (ch >= nch) return;
-  const int items = *count * nb64;
-  for (int it = blockIdx.x; it < items; it += gridDim.x) pfa_cols_block<TC, UNR>(Y, corr, stride, N1, N2, nch, T, zero_rows, list[it / nb64], it % nb64, ch);
-}
 
 }  // namespace pal

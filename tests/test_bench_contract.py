@@ -143,3 +143,23 @@ def test_bench_require_rccl_refuses_the_fallback():
     rc, line, err = queue.get(timeout=900)
     p.join(timeout=60)
     assert rc != 0 and "--require-rccl" in err, (rc, err[-500:])
+
+
+def test_counter_traffic_is_found_for_every_configuration():
+    """roofline.traffic comes from the committed counter passes of the SAME configuration (profiles/pmc_traffic.json for the
+    metric run, profiles/pmc_traffic_<config>.json for C2 ... C5); the profiler's kernel names carry more template arguments
+    than the engine's labels, the lookup bridges that (never None for a committed configuration)."""
+    import bench
+    table = {"k_pfa_rows_big<14,32>": 7, "k_colsreg2_fwd<48,13,PairLoader>": 9, "k_colsreg2_fwd<48,13,ChirpLoader>": 1, "k_pfa_cols_fin": 3}
+    assert bench.traffic_lookup(table, "k_pfa_rows_big<14>") == 7
+    assert bench.traffic_lookup(table, "k_colsreg_fwd<48,PairLoader>") == 9
+    assert bench.traffic_lookup(table, "k_pfa_cols_fin") == 3
+    assert bench.traffic_lookup(table, "k_rows<9,conv>") is None
+    for cfg in ("metric", "c2", "c3", "c4", "c5"):
+        tname = "pmc_traffic.json" if cfg == "metric" else f"pmc_traffic_{cfg}.json"
+        line = "r03_c_bench.json" if cfg == "metric" else f"r03_c_bench_{cfg}.json"
+        with open(os.path.join(ROOT, "profiles", tname)) as f:
+            counters = json.load(f)
+        with open(os.path.join(ROOT, "profiles", line)) as f:
+            dominant = json.loads(f.read().strip().splitlines()[-1])["roofline"]["kernel"]
+        assert bench.traffic_lookup(counters, dominant), (cfg, dominant)

@@ -12,6 +12,11 @@ ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# (PARTS: which parts to run - "metric", "configs" (CFGS, default c2 c3 c4 c5), "stream"; default all.  One gpurun call holds
+#  at most twenty minutes: `PARTS="metric" ...`, then `PARTS="configs stream" CFGS="c2 c3" ...`, ...)
+PARTS=${PARTS:-metric configs stream}
+CFGS=${CFGS:-c2 c3 c4 c5}
+if [[ " $PARTS " == *" metric "* ]]; then
 python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats.log 2>&1; echo "stats rc=$?"
 PMC_CMD="python3 $ROOT/bench.py --steps 2 --warmup 1 --frames 16 --no-cpu-baseline --no-kernel-events"
@@ -20,7 +25,10 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "flops SQ_INSTS_VALU_FMA_F64 S
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc/$name -o $name --output-format csv -- $PMC_CMD > $OUT/pmc_$name.log 2>&1 || echo "pass $name failed"
 done
 python3 $ROOT/tools/pmc_summary.py $OUT/pmc $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1
-for cfg in c2 c3 c4 c5; do
+python3 $ROOT/tools/flops_per_pair.py $OUT/pmc_flops.json $OUT/pmc_traffic.json 16 > $OUT/fp64_flops_per_pair.json
+fi
+if [[ " $PARTS " == *" configs "* ]]; then
+for cfg in $CFGS; do
   python3 $ROOT/bench.py --config $cfg --steps 10 --warmup 3 > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; echo "bench $cfg rc=$?"
   rocprofv3 --kernel-trace --stats -d $OUT/stats_$cfg -o stats --output-format csv -- python3 $ROOT/bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline > $OUT/stats_$cfg.log 2>&1
   # memory-side traffic and fp64 operations of the configuration's kernels: the same three counter passes as the metric run
@@ -31,9 +39,12 @@ for cfg in c2 c3 c4 c5; do
   done
   python3 $ROOT/tools/pmc_summary.py $OUT/pmc_$cfg $OUT/pmc_traffic_$cfg.json > $OUT/pmc_summary_$cfg.txt 2>&1
 done
+fi
+if [[ " $PARTS " == *" stream "* ]]; then
 python3 $ROOT/tools/bench_stream.py 128 2 > $OUT/stream.json 2> $OUT/stream.err; echo "stream rc=$?"
+fi
 find $OUT -name "*.db" -delete
 find $OUT -name "*_kernel_trace.csv" -size +8M -delete
 find $OUT -name "*counter_collection.csv" -size +8M -delete
 ls $OUT | head -40
-tail -c 400 $OUT/bench.json
+[ -f $OUT/bench.json ] && tail -c 400 $OUT/bench.json
