@@ -108,6 +108,11 @@ int pal_gcc_phat_all_pairs(pal_handle h, const double* frames, int B, int M, int
                            pal_pair_record* table, double* corr);
 int pal_gcc_phat_all_pairs_dev(pal_handle h, const double* d_frames, int B, int M, int L, const pal_phat_params* prm,
                                pal_pair_record* d_table);
+/* Ordering of the _dev forms: everything is enqueued on the engine's streams and the results are complete after
+ * pal_synchronize.  With one peak per row (num_peaks = 1) and no corr the column pass finishes the rows itself
+ * (csrc/pfa_cols_fin.h); the call then reads ONE integer back at its end (the number of rows that need the stored-row
+ * path - a tie, a peak at the lag window's edge: typically 0.1 % - which it resolves before returning), i.e. it blocks
+ * the host for the duration of its own device work.  PAL_FIN=0 keeps the call fully asynchronous (stored rows + finish launch). */
 /* Non-finite samples: the reference confines a NaN to the pairs of its own microphone.  Here two pairs share one complex
  * transform, so a frame with a NaN or an infinity makes the batched calls (all_pairs, pairs) fail with PAL_ERR_INVALID
  * (reported by the call itself, or by pal_synchronize for the _dev forms) instead of returning rows that differ from the
