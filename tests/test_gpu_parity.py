@@ -256,6 +256,60 @@ def test_fused_column_pass_matches_separate_launches_and_oracle(engine, length, 
         assert np.allclose(t1[b]["snr"], want["snr"], rtol=1e-9, atol=0)
 
 
+# the finishing column pass (csrc/pfa_cols_fin.h, pfa_fin_lean.h) in each of its forms: (length, n1, n2, environment)
+FIN_CASES = [(44100, 89, 991, {}),                              # Rader-89 columns, four wavefronts
+             (44113, 25, 3529, {}),                             # dense columns, two chunks = two wavefronts
+             (44110, 47, 1877, {}),                             # dense columns, three chunks = three wavefronts, unused output indices
+             (44254, 67, 1321, {}),                             # dense columns, four chunks
+             (44103, 23, 3835, {}),                             # strips (one chunk, four strips per block)
+             (44101, 0, 0, {"PAL_FIN_FOUR": "1"})]              # four-step last pass (opt-in): the last grid row is partial
+
+
+@pytest.mark.parametrize("length,n1,n2,env", FIN_CASES, ids=[f"L{c[0]}" for c in FIN_CASES])
+def test_finishing_column_pass_equals_stored_rows(engine, length, n1, n2, env, monkeypatch):
+    """Records of the pass that never stores the correlation rows against the stored-row path (PAL_FIN=0), field by field, for
+    noise, delayed copies, a tone (fallback branches) and a silent microphone; windowed and not; 'median' through the bound
+    (multiplier 1), through histogram windows (4.2) and 'adaptive'.  Integer fields bit-exact; float fields to 1e-11 (sums in
+    another order).  The pass must really have run (profile entries)."""
+    from pyaudiolocalization_amd import Engine
+    assert _plan_of(engine, length) == (n1, n2)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(length)
+    mics, fs = 5, 44100.0
+    base = rng.standard_normal(length + 64)
+    cases = {"noise": rng.standard_normal((1, mics, length)),
+             "delayed": (np.stack([base[d:d + length] for d in rng.integers(0, 64, mics)]) + 0.3 * rng.standard_normal((mics, length)))[None],
+             "tone": (np.sin(0.05 * np.arange(length))[None, :] + 0.3 * rng.standard_normal((mics, length)))[None]}
+    silent = rng.standard_normal((1, mics, length))
+    silent[0, 1] = 0.0
+    cases["silent"] = silent
+    monkeypatch.setenv("PAL_FIN", "1")
+    fin = Engine(engine.device)
+    monkeypatch.setenv("PAL_FIN", "0")
+    stored = Engine(engine.device)
+    try:
+        for name, fr in cases.items():
+            for med in (0.05, None):
+                for method, mult in (("median", 1.0), ("median", 4.2), ("adaptive", 1.0)):
+                    if n1 == 0 and mult > 2.0:
+                        continue                                # (the four-step pass has no histogram form: stored rows both ways)
+                    fin.profile_begin()
+                    ta = fin.gcc_phat_all_pairs(fr, fs, 1, method, mult, med)
+                    fin.profile_end()
+                    ent = fin.profile_entries()
+                    assert any(k.startswith("k_pfa_cols_fin") or k.startswith("k_colsreg_fin") for k in ent), (name, med, method, mult, sorted(ent))
+                    tb = stored.gcc_phat_all_pairs(fr, fs, 1, method, mult, med)
+                    tag = (name, med, method, mult)
+                    for f in ("k_sel", "branch", "k_argmax", "n_sel"):
+                        assert np.array_equal(ta[f], tb[f]), (tag, f)
+                    for f in ("cmax", "cmin", "snr", "sel_height"):
+                        assert np.allclose(ta[f], tb[f], rtol=1e-11, atol=1e-300), (tag, f)
+    finally:
+        fin.close()
+        stored.close()
+
+
 def test_fused_column_pass_plateaus_and_grid_edges(engine, monkeypatch):
     """Samples with equal neighbours and peaks in the grid's first / last column (lags m = 0 or N2 - 1 mod N2) take the
     finish launch's own tests: quantised inputs give exact ties, and the window is the whole row."""
