@@ -556,7 +556,7 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
   }
   // the finishing column pass (pfa_cols_fin.h) writes one flag per pair: 1 = resolved at the end of this call from stored rows
   const bool fin = table && !split && !corr_out && !ksel_multi &&
-                   (pfa ? pfa_sub == 0 && pfa_can_fuse(pl) && pfa_can_finish(pl, prm) : fourstep_can_finish(pl, prm));
+                   (pfa ? pfa_sub == 0 && pfa_can_finish(pl, prm) : fourstep_can_finish(pl, prm));
   int* need = nullptr;
   if (fin) {
     void* np = nullptr;

@@ -387,6 +387,14 @@ bool Engine::pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const {
   bool cols_ok = f.r89 != nullptr || (f.nch >= 2 && f.nch <= 4) || (f.nch <= 1 && f.lm <= 13);
   if (dense_env) cols_ok = f.r89 != nullptr || atoi(dense_env) != 0;
   if (f.nch <= 1 && strips) cols_ok = true;
+  // five and six chunks (N1 up to 133: C5's 103 x 233; five- / six-wavefront blocks, no histogram form): opt-in, PAL_FIN_WIDE=1.
+  // Correct, but C5 runs 2.53 against 2.58 M pairs/s with it: 960 blocks are one round of the machine, every wavefront is in the
+  // same phase at the same time and the pass (160 us) is the sum of its latencies, where the separate launches (70 + 18 + 31 + 32) overlap
+  const bool nohist = prm.threshold_method > 0 || (prm.threshold_multiplier >= 0 && prm.threshold_multiplier <= 2.0 && getenv("PAL_FIN_HIST") == nullptr);
+  if (f.nch >= 5) {
+    static const bool wide = getenv("PAL_FIN_WIDE") != nullptr && atoi(getenv("PAL_FIN_WIDE")) != 0;
+    return fin_cols && wide && fuse_peaks && f.on() && f.nch <= 6 && nohist && prm.num_peaks == 1 && f.n2 >= 124;
+  }
   return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.n2 >= 256 && cols_ok;
 }
 
@@ -415,9 +423,9 @@ int Engine::fin_setup(const Plan& pl, int rows, int nblk, int grid_rows, int gri
   // per-stream scratch of the finishing pass: [done words G x blocks | emax | parts | edge]
   const int Gmax = pair_group(n);
   // (`done` words and FinPartial entries: room for one per WAVEFRONT of a block, pfa_fin_lean.h)
-  const size_t off_emax = (size_t(Gmax) * nblk * 4 * sizeof(unsigned) + 127) & ~size_t(127);
-  const size_t off_parts = (off_emax + size_t(2 * Gmax) * nblk * 8 * sizeof(double) + 127) & ~size_t(127);
-  const size_t off_edge = (off_parts + size_t(2 * Gmax) * nblk * 4 * sizeof(FinPartial) + 127) & ~size_t(127);
+  const size_t off_emax = (size_t(Gmax) * nblk * 6 * sizeof(unsigned) + 127) & ~size_t(127);
+  const size_t off_parts = (off_emax + size_t(2 * Gmax) * nblk * 12 * sizeof(double) + 127) & ~size_t(127);
+  const size_t off_edge = (off_parts + size_t(2 * Gmax) * nblk * 6 * sizeof(FinPartial) + 127) & ~size_t(127);
   const size_t total = off_edge + size_t(2 * Gmax) * 4 * grid_rows * sizeof(double);
   void* sp = nullptr;
   PAL_TRY(scratch(16 + slot, total, &sp));
@@ -526,7 +534,8 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
     const bool full = (f.n1 - 1) / 2 == f.nch * kPfaTC;
     // histograms only where the bound sqrt(2 mean(x^2)) on the median cannot decide: multipliers above 2 (or negative)
     const bool hist = !(a.method > 0 || fa.cheb);
-    const int nw = f.nch == 2 ? 2 : (f.nch == 3 && !hist ? 3 : 4);   // (three chunks: three wavefronts where the statistics are per wavefront)
+    const int nw = f.nch == 2 ? 2 : (f.nch == 3 && !hist ? 3 : (f.nch >= 5 ? f.nch : 4));   // (three chunks: three wavefronts where the statistics are per wavefront)
+    if (f.nch >= 5 && hist) return fail(PAL_ERR_INTERNAL, "finishing column pass with %d chunks and histograms", f.nch);
     FinSrc src{Y, f.T, static_cast<const Rader89Tab*>(f.r89), nullptr, nullptr, nullptr};
     PAL_TRY(fin_serialize(on));
 #define PAL_COLS_FIN(MODE, HI, FU, NW) k_pfa_cols_fin<MODE, kPfaTC, kPfaUnr, HI, FU, NW><<<grid, dim3(64 * NW), 0, on>>>(src, f.n1, f.n2, G, f.nch, nblk, zero_rows, a, fa, rows)
@@ -538,6 +547,10 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
       else { if (full) PAL_COLS_FIN(kColsDense, false, true, 2); else PAL_COLS_FIN(kColsDense, false, false, 2); }
     } else if (nw == 3) {
       if (full) PAL_COLS_FIN(kColsDense, false, true, 3); else PAL_COLS_FIN(kColsDense, false, false, 3);
+    } else if (nw == 5) {
+      if (full) PAL_COLS_FIN(kColsDense, false, true, 5); else PAL_COLS_FIN(kColsDense, false, false, 5);
+    } else if (nw == 6) {
+      if (full) PAL_COLS_FIN(kColsDense, false, true, 6); else PAL_COLS_FIN(kColsDense, false, false, 6);
     } else {
       if (hist) { if (full) PAL_COLS_FIN(kColsDense, true, true, 4); else PAL_COLS_FIN(kColsDense, true, false, 4); }
       else { if (full) PAL_COLS_FIN(kColsDense, false, true, 4); else PAL_COLS_FIN(kColsDense, false, false, 4); }

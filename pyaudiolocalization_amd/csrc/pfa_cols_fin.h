@@ -412,6 +412,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
   constexpr int TC = FOUR ? 1 : P1, UNR = FOUR ? 1 : P2;
   static_assert(!R89 || (NW == 4 && FULL), "the Rader column transform is the four-wavefront N1 = 89 case");
   static_assert(!FOUR || !HIST, "the four-step last pass finishes its rows without histograms only");
+  static_assert(!HIST || NW <= 4, "the histogram form merges at most four wavefronts per block");
   const cd* __restrict__ Y = src.Y;
   const double* __restrict__ T = src.T;
   const Rader89Tab* __restrict__ tab = src.tab;
