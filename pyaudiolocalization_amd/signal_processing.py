@@ -80,19 +80,79 @@ def dynamic_range_compression_soft_clip(signal: np.ndarray, threshold: float = 0
     return np.where(mag > threshold, np.sign(x) * (threshold + (mag - threshold) * 0.5), x)
 
 
+_KAISER_BEST = {}
+
+
+def _kaiser_best_filter():
+    """Right wing of the `kaiser_best` interpolation filter from its published design parameters (resampy's documentation of
+    its shipped filters): a Kaiser-windowed sinc with 64 zero crossings, 2^9 table entries per crossing, beta =
+    14.769656459379492 and roll-off 0.9475937167399596.  resampy ships the table as a data file; this one is generated."""
+    if not _KAISER_BEST:
+        from scipy.signal.windows import kaiser  # noqa: PLC0415
+        num_zeros, precision, beta, rolloff = 64, 9, 14.769656459379492, 0.9475937167399596
+        num_table = 2 ** precision
+        n = num_table * num_zeros
+        sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+        taper = kaiser(2 * n + 1, beta)[n:]                       # right half of the symmetric window
+        _KAISER_BEST["win"] = taper * sinc_win
+        _KAISER_BEST["num_table"] = num_table
+    return _KAISER_BEST["win"], _KAISER_BEST["num_table"]
+
+
+def resample_kaiser_best(data: np.ndarray, original_fs: float, target_fs: float) -> np.ndarray:
+    """Band-limited sinc interpolation along the last axis in the form resampy publishes for `resample(..., filter=
+    'kaiser_best')` (Smith's algorithm): output sample t sits at time t / ratio of the input; both wings of the
+    windowed sinc are walked in steps of `scale x table entries` with linear interpolation between table entries, the
+    filter is scaled by the ratio when downsampling, and the output has int(n x ratio) samples.  Vectorised over the
+    output samples (one pass per filter tap).  PARITY UNPINNED: resampy is not importable here, there is no output of it
+    to compare with - tests/test_ingest_host.py checks band-limited reconstruction and the published conventions."""
+    x = np.asarray(data, dtype=np.float64)
+    ratio = float(target_fs) / float(original_fs)
+    if ratio <= 0:
+        raise ValueError("Invalid sample rates")
+    n_orig = x.shape[-1]
+    n_out = int(n_orig * ratio)
+    if n_out < 1:
+        raise ValueError(f"Input signal length={n_orig} is too small to resample from {original_fs}->{target_fs}")
+    win, num_table = _kaiser_best_filter()
+    interp_win = win * ratio if ratio < 1 else win
+    interp_delta = np.diff(interp_win, append=interp_win[-1])
+    scale = min(1.0, ratio)
+    index_step = int(scale * num_table)
+    nwin = interp_win.shape[0]
+    t_reg = np.arange(n_out) * (1.0 / ratio)
+    n = t_reg.astype(np.int64)
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, n_orig)
+    y = np.zeros((x2.shape[0], n_out))
+
+    def wing(frac, count, sign, first):
+        index_frac = frac * num_table
+        offset = index_frac.astype(np.int64)
+        eta = index_frac - offset
+        taps = np.minimum(count, (nwin - offset) // index_step)
+        for i in range(int(taps.max()) if taps.size else 0):
+            live = i < taps
+            idx = np.where(live, offset + i * index_step, 0)
+            weight = np.where(live, interp_win[idx] + eta * interp_delta[idx], 0.0)
+            src = np.where(live, first + sign * i, 0)
+            y[:, :] += weight[None, :] * x2[:, src]
+
+    frac = scale * (t_reg - n)
+    wing(frac, n + 1, -1, n)                                      # left wing: x[n], x[n - 1], ...
+    wing(scale - frac, n_orig - n - 1, +1, n + 1)                 # right wing: x[n + 1], x[n + 2], ...
+    return y.reshape(lead + (n_out,))
+
+
 def resample_audio(data: np.ndarray, original_fs: float, target_fs: float) -> np.ndarray:
     """signal_processing.py:105-107 (outside the hot path): resampy's kaiser_best when that optional package
-    is installed.  Without it (the build image): SciPy's polyphase resampler with a Kaiser window - band-limited to the
-    same purpose but NOT sample-identical to resampy (parity unpinned: no resampy output exists here to compare with)."""
+    is installed; without it (the build image) the own implementation of the same published algorithm and filter design
+    (`resample_kaiser_best`: parity unpinned, no resampy output exists here to compare with)."""
     try:
         import resampy  # noqa: PLC0415 - optional dependency
         return resampy.resample(data, original_fs, target_fs, filter="kaiser_best")
     except ImportError:
-        from fractions import Fraction  # noqa: PLC0415
-        from scipy.signal import resample_poly  # noqa: PLC0415
-        logging.getLogger(__name__).warning("resampy is not installed: resampling with scipy.signal.resample_poly (Kaiser window)")
-        ratio = Fraction(float(target_fs) / float(original_fs)).limit_denominator(1000)
-        return resample_poly(np.asarray(data, dtype=np.float64), ratio.numerator, ratio.denominator, window=("kaiser", 14.769656459379492))
+        return resample_kaiser_best(data, original_fs, target_fs)
 
 
 def _filter_design(fs: float, method: str, lowcut: float, highcut: float, filter_order: int):
