@@ -90,6 +90,14 @@ struct Engine {
   int fin_done(hipStream_t on);
   bool fin_pending = false;
   bool fin_serial = false;         // PAL_FIN_SERIAL=1
+  // diagnostic switches of the finishing pass, read when the engine is created (not once per process: tests build engines
+  // under different settings)
+  int fin_dense = -1;              // PAL_FIN_DENSE: 1 / 0 = the pass on every / no dense column DFT; -1 (unset): where it measured faster
+  bool fin_strips = false;         // PAL_FIN_STRIPS=1: also on short columns beside 16384-point row tiles
+  bool fin_four = false;           // PAL_FIN_FOUR=1: on the four-step last pass
+  bool fin_wide = false;           // PAL_FIN_WIDE=1: on column DFTs of five or six chunks
+  bool fin_hist = false;           // PAL_FIN_HIST=1: histogram windows for every threshold multiplier
+  int debug_memo = 0;              // PAL_DEBUG_MEMO=<n>: shrinks the distance rule's on-chip memo / stack (tests of its slow path)
   hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams
   int overlap = 3;                 // PAL_OVERLAP: 0 one stream; 1 launch groups alternate between two streams; 2 transforms on
                                    // `stream`, peak selection on `stream2`; 3 (default) groups rotate over three streams

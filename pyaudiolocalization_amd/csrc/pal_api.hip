@@ -276,6 +276,16 @@ int pal_create(int device, pal_handle* out) {
   if (env) e->fin_serial = atoi(env) != 0;
   env = getenv("PAL_FIN");
   if (env) e->fin_cols = atoi(env) != 0;
+  env = getenv("PAL_FIN_DENSE");
+  if (env) e->fin_dense = atoi(env) != 0 ? 1 : 0;
+  e->fin_strips = getenv("PAL_FIN_STRIPS") != nullptr;
+  env = getenv("PAL_FIN_FOUR");
+  e->fin_four = env && atoi(env) != 0;
+  env = getenv("PAL_FIN_WIDE");
+  e->fin_wide = env && atoi(env) != 0;
+  e->fin_hist = getenv("PAL_FIN_HIST") != nullptr;
+  env = getenv("PAL_DEBUG_MEMO");
+  if (env) e->debug_memo = atoi(env);
   env = getenv("PAL_PFA_SUB");
   if (env) e->pfa_sub = atoi(env);
   env = getenv("PAL_MAX_PLANS");

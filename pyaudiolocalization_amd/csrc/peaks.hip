@@ -1348,7 +1348,7 @@ int Engine::peaks_setup(const double* corr, size_t stride, int rows, int n, int 
   a.bh = reinterpret_cast<BlockHist*>(base + off_list);
   a.bits = corr ? reinterpret_cast<unsigned*>(base + off_bits) : nullptr;
   {
-    static const int dbg = getenv("PAL_DEBUG_MEMO") ? atoi(getenv("PAL_DEBUG_MEMO")) : 0;     // (tests: a tiny memo sends every chain to the slow path)
+    const int dbg = debug_memo;                                // (PAL_DEBUG_MEMO, tests: a tiny memo sends every chain to the slow path)
     a.memo_cap = dbg > 0 && dbg < kMemo ? dbg : kMemo;
     a.stack_cap = dbg > 0 && dbg < kStack ? dbg : kStack;
   }

@@ -378,22 +378,20 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
 // the blocks and the serial finish cost more than the stores and the finish launch they replace (C3: 0.95 against 1.11 M pairs/s).
 bool Engine::pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const {
   const Pfa& f = pl.pfa;
-  static const bool strips = getenv("PAL_FIN_STRIPS") != nullptr;
-  static const char* dense_env = getenv("PAL_FIN_DENSE");     // 1 / 0: the pass on every / no dense column DFT (default: by measurement)
+  const bool strips = fin_strips;
   // Measured over L = 44100 ... 44299 with the per-wavefront statistics of pfa_fin_lean.h (profiles/r03_c_length_sweep_dense_fin.csv
   // against ..._default.csv): the pass wins with Rader-89 columns (+10 %), with two or four chunks of output indices (+3 ... +12 %, +4 %)
   // and with short columns beside row tiles of up to 8192 points (+8 %); three chunks leave the fourth wavefront idle (-2 %), and
   // beside the 16384-point row tiles it is a wash
   bool cols_ok = f.r89 != nullptr || (f.nch >= 2 && f.nch <= 4) || (f.nch <= 1 && f.lm <= 13);
-  if (dense_env) cols_ok = f.r89 != nullptr || atoi(dense_env) != 0;
+  if (fin_dense >= 0) cols_ok = f.r89 != nullptr || fin_dense != 0;      // PAL_FIN_DENSE=1 / 0: every / no dense column DFT
   if (f.nch <= 1 && strips) cols_ok = true;
   // five and six chunks (N1 up to 133: C5's 103 x 233; five- / six-wavefront blocks, no histogram form): opt-in, PAL_FIN_WIDE=1.
   // Correct, but C5 runs 2.53 against 2.58 M pairs/s with it: 960 blocks are one round of the machine, every wavefront is in the
   // same phase at the same time and the pass (160 us) is the sum of its latencies, where the separate launches (70 + 18 + 31 + 32) overlap
-  const bool nohist = prm.threshold_method > 0 || (prm.threshold_multiplier >= 0 && prm.threshold_multiplier <= 2.0 && getenv("PAL_FIN_HIST") == nullptr);
+  const bool nohist = prm.threshold_method > 0 || (prm.threshold_multiplier >= 0 && prm.threshold_multiplier <= 2.0 && !fin_hist);
   if (f.nch >= 5) {
-    static const bool wide = getenv("PAL_FIN_WIDE") != nullptr && atoi(getenv("PAL_FIN_WIDE")) != 0;
-    return fin_cols && wide && fuse_peaks && f.on() && f.nch <= 6 && nohist && prm.num_peaks == 1 && f.n2 >= 124;
+    return fin_cols && fin_wide && fuse_peaks && f.on() && f.nch <= 6 && nohist && prm.num_peaks == 1 && f.n2 >= 124;
   }
   return fin_cols && pfa_can_fuse(pl) && prm.num_peaks == 1 && f.n2 >= 256 && cols_ok;
 }
@@ -470,7 +468,7 @@ int Engine::fin_setup(const Plan& pl, int rows, int nblk, int grid_rows, int gri
       fa.win_hi = int(hi > n - 2 ? n - 2 : hi);
     }
   }
-  static const bool no_cheb = getenv("PAL_FIN_HIST") != nullptr;    // diagnostics: histograms for every multiplier
+  const bool no_cheb = fin_hist;                               // diagnostics: histograms for every multiplier
   fa.cheb = a.method == 0 && prm.threshold_multiplier >= 0 && prm.threshold_multiplier <= 2.0 && !no_cheb ? 1 : 0;
   fa.stamps = nullptr;
   static const bool want_stamps = getenv("PAL_DEBUG_STAMPS") != nullptr;
@@ -488,8 +486,8 @@ int Engine::fin_setup(const Plan& pl, int rows, int nblk, int grid_rows, int gri
 // M1 <= 24), one peak per row is asked for and the threshold needs no histograms ('adaptive', or 'median' with a multiplier in 0 .. 2)
 bool Engine::fourstep_can_finish(const Plan& pl, const pal_phat_params& prm) const {
   const Conv& c = pl.inv;
-  static const bool off = getenv("PAL_FIN_FOUR") == nullptr || atoi(getenv("PAL_FIN_FOUR")) == 0;   // opt-in: measured 0.38 against 0.49 M pairs/s for the stored rows + statistics launches
-  const bool nohist = prm.threshold_method > 0 || (prm.threshold_multiplier >= 0 && prm.threshold_multiplier <= 2.0 && getenv("PAL_FIN_HIST") == nullptr);
+  const bool off = !fin_four;                                  // opt-in (PAL_FIN_FOUR=1): measured 0.36 against 0.50 M pairs/s for the stored rows + statistics launches
+  const bool nohist = prm.threshold_method > 0 || (prm.threshold_multiplier >= 0 && prm.threshold_multiplier <= 2.0 && !fin_hist);
   return fin_cols && !off && c.reg && c.M1() <= 24 && prm.num_peaks == 1 && nohist && pl.nout == pl.n;
 }
 
