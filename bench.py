@@ -470,9 +470,9 @@ def main() -> None:
     flops = fp64_flops_per_pair(info, m, length)
     flops_source = "operation count of the kernels' structure (DESIGN.md section 5), FMA = 2"
     mpath = os.path.join(ROOT, "profiles", "fp64_flops_per_pair.json")
-    if args.config == "metric" and length == 44100 and m == 64 and os.path.exists(mpath):
+    if not args.mics and not args.length and os.path.exists(mpath):
         try:                                                       # measured instruction counts of an earlier PMC pass of this workload
-            rec = json.load(open(mpath))["metric"]
+            rec = json.load(open(mpath))[args.config]
             flops = float(rec["fp64_flops_per_pair"])
             flops_source = "measured: fp64 instruction counters of an earlier PMC pass of this command, NOT this run (profiles/fp64_flops_per_pair.json)"
         except Exception:
