@@ -557,8 +557,10 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
   // the finishing column pass (pfa_cols_fin.h) writes one flag per pair: 1 = resolved at the end of this call from stored rows
   const bool fin = table && !split && !corr_out && !ksel_multi &&
                    (pfa ? pfa_sub == 0 && pfa_can_finish(pl, prm) : fourstep_can_finish(pl, prm));
+  // stored rows + per-wavefront statistics (pfa_fin_lean.h with FinArgs.corr): the caller wants corr, or the plan has no finishing form
+  const bool lean = !fin && pfa && table && !split && !ksel_multi && pfa_sub == 0 && pfa_can_lean_store(pl, prm);
   int* need = nullptr;
-  if (fin) {
+  if (fin || lean) {
     void* np = nullptr;
     PAL_TRY(scratch(19, (size_t(2 * npairs) + 64) * sizeof(int), &np));     // [flags | list | count]
     need = static_cast<int*>(np);
@@ -582,7 +584,10 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
     double* crow = via_scratch ? cbuf + size_t(slot) * buf_doubles : corr_out + size_t(p0) * stride;
     if (split && group >= 2) PAL_HIP(hipStreamWaitEvent(stream, ev_peaks[slot], 0));   // group - 2 is done with this buffer
     const bool fused = pfa && table && !split && pfa_sub == 0 && pfa_can_fuse(pl);
-    if (fin && pfa) {
+    if (lean) {
+      PAL_TRY(pfa_pair_group_fin(pl, permuted, quads + t0, G, rows, Wg, zero_rows ? zero_rows + p0 : nullptr, prm, n2, table + p0, need + p0,
+                                 slot, on, crow, stride));
+    } else if (fin && pfa) {
       // nobody reads the correlation rows: the column pass finishes them without storing them (pfa_cols_fin.h)
       PAL_TRY(pfa_pair_group_fin(pl, permuted, quads + t0, G, rows, Wg, zero_rows ? zero_rows + p0 : nullptr, prm, n2, table + p0, need + p0,
                                  slot, on));
@@ -619,7 +624,7 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
       PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[slot], 0));
       pon = stream2;
     }
-    if (table && !fused && !fin)
+    if (table && !fused && !fin && !lean)
       PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr, pon));
     if (split) PAL_HIP(hipEventRecord(ev_peaks[slot], stream2));
     return PAL_OK;
@@ -648,7 +653,7 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
       PAL_HIP(hipStreamWaitEvent(stream, ev_join3, 0));
     }
   }
-  if (fin) {
+  if (fin || lean) {
     // The pairs the finishing blocks flagged (a threshold comparison inside the median's interval, a tie, a window peak next to
     // the window's edge, ...) go through the stored-row path now, packed in pair order.  The count comes to the host: this
     // is the one synchronisation of the call (its launch groups above never waited for the host).

@@ -450,6 +450,8 @@ int Engine::fin_setup(const Plan& pl, int rows, int nblk, int grid_rows, int gri
   fa.status = status;
   // the lag window |m - (n2 - 1)| / fs <= max_expected_delay (utils.py:163) as sample indices, with the reference's arithmetic
   fa.pw = 1;
+  fa.corr = nullptr;
+  fa.stride = 0;
   fa.windowed = std::isnan(prm.max_expected_delay) ? 0 : 1;
   fa.win_lo = 1;
   fa.win_hi = n - 2;
@@ -515,8 +517,24 @@ int Engine::fourstep_pair_group_fin(const Plan& pl, const cd* W, int G, int rows
   return PAL_OK;
 }
 
+// The same pass with the correlation rows stored as well (the caller wants them, or the plan has no finishing form that pays):
+// per-wavefront statistics, no sibling polls, the finisher reads the SNR window from the stored row; flagged rows are resolved at the
+// end of the call like the finishing pass's.  Replaces pfa_cols_stats.h / the three statistics launches + k_peak_finish where one
+// peak per row is asked for and the threshold needs no histograms.
+bool Engine::pfa_can_lean_store(const Plan& pl, const pal_phat_params& prm) const {
+  const Pfa& f = pl.pfa;
+  const bool nohist = prm.threshold_method > 0 || (prm.threshold_multiplier >= 0 && prm.threshold_multiplier <= 2.0 && !fin_hist);
+  // Several rounds of column blocks per launch group, or the pass is the sum of one block's latencies: C5 (103 x 233: four blocks per
+  // transform, 960 per group, one round) measured 2.32 against 2.60 M pairs/s with it; C3 (7 x 6857: 28 blocks) 1.16 against 1.08,
+  // C2 (17 x 5647: 23 blocks) 0.422 against 0.417
+  const int nblk = (f.n2 + (f.nch <= 1 ? 4 : 1) * kColsOwn - 1) / ((f.nch <= 1 ? 4 : 1) * kColsOwn);
+  // (five and six chunks, N1 = 91 ... 127 beside 700 - 970 columns: 0.63 - 0.66 against 0.69 - 0.71 M with it: they keep the three statistics launches)
+  return lean_store && fin_cols && fuse_peaks && f.on() && f.nch >= 1 && f.nch <= 4 && nblk >= 12 && prm.num_peaks == 1 && nohist;
+}
+
 int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, const int* zero_rows,
-                               const pal_phat_params& prm, int n2, pal_pair_record* table, int* need, int slot, hipStream_t on) {
+                               const pal_phat_params& prm, int n2, pal_pair_record* table, int* need, int slot, hipStream_t on,
+                               double* corr, size_t stride) {
   const Pfa& f = pl.pfa;
   const bool shortcols = f.nch <= 1;                           // short column DFTs (N1 <= 23): the four wavefronts of a block are four strips
   const int nblk = (f.n2 + (shortcols ? 4 : 1) * kColsOwn - 1) / ((shortcols ? 4 : 1) * kColsOwn);
@@ -524,10 +542,12 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
   FinArgs fa;
   unsigned nwg = 0;
   PAL_TRY(fin_setup(pl, rows, nblk, f.n1, f.n2, prm, n2, table, need, slot, on, a, fa, nwg, G));
+  fa.corr = corr;
+  fa.stride = stride;
   static const bool want_stamps = getenv("PAL_DEBUG_STAMPS") != nullptr;
   PAL_TRY(pfa_rows(pl, permuted, quads, G, Y, on));
   {
-    ProfScope ps(this, "k_pfa_cols_fin", on);
+    ProfScope ps(this, corr ? "k_pfa_cols_lean" : "k_pfa_cols_fin", on);
     const dim3 grid(nwg);
     const bool full = (f.n1 - 1) / 2 == f.nch * kPfaTC;
     // histograms only where the bound sqrt(2 mean(x^2)) on the median cannot decide: multipliers above 2 (or negative)

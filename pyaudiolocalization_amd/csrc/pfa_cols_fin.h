@@ -62,7 +62,9 @@ struct FinArgs {
   int* status;                    // engine status words (bit 2 of word 0: a wait timed out; word 4: flagged rows)
   int win_lo, win_hi;             // lag window as sample indices, |m - (n2 - 1)| / fs <= max_expected_delay (win_lo > win_hi: empty)
   int windowed;
-  int pw;                         // FinPartial entries and `done` words per column block: 1, or 4 = one per wavefront (pfa_fin_lean.h)
+  int pw;                         // FinPartial entries and `done` words per column block: 1, or one per wavefront (pfa_fin_lean.h)
+  double* corr;                   // null, or [rows][stride]: the pass ALSO stores the correlation rows (the caller wants them, or the plan
+  size_t stride;                  //   has no finishing form): nobody polls siblings then, the finisher reads the SNR window from the stored row
   int cheb;                       // 1: no histograms - the median of |corr| is bounded by sqrt(2 mean(corr^2)) (see fin_row)
   unsigned long long* stamps;     // diagnostics (PAL_DEBUG_STAMPS=1): [workgroup][8] 100 MHz clock reads of lane 0 per phase
 };

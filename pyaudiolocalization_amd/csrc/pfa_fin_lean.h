@@ -269,6 +269,21 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[NS], const cd c0, co
     }
   }
 
+  // ---- stored-row form (FinArgs.corr): the samples go to HBM as well, and nothing below waits for a sibling - the finisher reads
+  //      the SNR window around the row's maximum from the stored row
+  const bool stored = fa.corr != nullptr;
+  if (stored) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (r >= nrow) continue;
+      double* const out = fa.corr + size_t(2 * g + r) * fa.stride + m2;
+      for_slots(r, [&](double x, int slot) {
+        const int t = T(slot);
+        if (own && (!PART || N2 * t + m2 < n)) out[size_t(N2) * t] = x;
+      });
+    }
+  }
+
   // ---- the lanes' sums and minima, once: rows 2 g and 2 g + 1 share a butterfly (even lanes end with row 2 g's total, odd
   //      lanes with the other row's).  They stand HERE so that the siblings' maxima have more time to arrive
   const double rmin = wave_pair_min(vn[0], vn[1]);
@@ -280,7 +295,7 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[NS], const cd c0, co
   bool have_w[2] = {false, false};
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    if (r >= nrow) continue;
+    if (r >= nrow || stored) continue;                         // (uniform)
     const int row = 2 * g + r;
     double bv = -INFINITY;
     int bi = -1;
@@ -422,6 +437,18 @@ __device__ __forceinline__ void fin_row_wave(const PeakArgs& pa, const FinArgs& 
   int why = 0;                                                 // (diagnostics: which rule flagged it)
   if (imax < 0 || imax >= n) { imax = 0; flag = true; why |= 1; }
   if (abandoned) { flag = true; why |= 1; }
+  if (fa.corr) {                                               // stored-row form: the SNR window from the row itself (written by this XCD's blocks)
+    const int lo = imax - pa.snr_w > 0 ? imax - pa.snr_w : 0, hi = imax + pa.snr_w < n ? imax + pa.snr_w : n;
+    const double* rowp = fa.corr + size_t(row) * fa.stride;
+    double u1 = 0, u2 = 0;
+    for (int k = lo + lane; k < hi; k += 64) {
+      const double x = ld_agent(rowp + k);
+      u1 += x;
+      u2 = __builtin_fma(x, x, u2);
+    }
+    w1 = wave_bcast63(wave_sum63(u1));
+    w2 = wave_bcast63(wave_sum63(u2));
+  }
   // a tie that may outrank the best strict peak (plateaus are resolved from the stored row)
   if (plat > -INFINITY && (mb < 0 || plat >= hb)) { flag = true; why |= 2; }
   if (windowed && platw > -INFINITY && (mw < 0 || platw >= hw)) { flag = true; why |= 4; }

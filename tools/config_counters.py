@@ -12,7 +12,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03_c"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 path = os.path.join(root, "fp64_flops_per_pair.json")
 out = json.load(open(path))
-PIPE = ("k_pfa_rows", "k_pfa_cols", "k_peak_", "PairLoader", "CorrStorer")
+PIPE = ("k_pfa_rows", "k_pfa_cols", "k_peak_", "k_flag_", "PairLoader", "CorrStorer")
 for cfg in ("c2", "c3", "c4", "c5"):
     line = json.loads(open(os.path.join(root, f"{tag}_bench_{cfg}.json")).read().strip().splitlines()[-1])
     per_launch = line["roofline"]["pairs_per_launch"]
