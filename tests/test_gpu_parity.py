@@ -310,6 +310,42 @@ def test_finishing_column_pass_equals_stored_rows(engine, length, n1, n2, env, m
         stored.close()
 
 
+@pytest.mark.parametrize("length,fs", [(24000, 48000.0), (44100, 44100.0)], ids=["strips-7x6857", "rader89-89x991"])
+def test_stored_row_pass_with_wavefront_statistics_equals_round2_statistics(engine, length, fs, monkeypatch):
+    """Where the rows are stored (the caller wants corr, or the plan has no finishing form) the column pass carries the
+    per-wavefront statistics and its finisher reads the SNR window from the stored row (k_pfa_cols_lean, PAL_LEAN_STORE default):
+    records and rows against pfa_cols_stats.h + k_peak_finish (PAL_LEAN_STORE=0)."""
+    from pyaudiolocalization_amd import Engine
+    rng = np.random.default_rng(length + 1)
+    mics = 5
+    base = rng.standard_normal(length + 64)
+    cases = {"noise": rng.standard_normal((2, mics, length)),
+             "delayed": (np.stack([base[d:d + length] for d in rng.integers(0, 64, mics)]) + 0.3 * rng.standard_normal((mics, length)))[None],
+             "tone": (np.sin(0.05 * np.arange(length))[None, :] + 0.3 * rng.standard_normal((mics, length)))[None]}
+    monkeypatch.setenv("PAL_LEAN_STORE", "1")
+    lean = Engine(engine.device)
+    monkeypatch.setenv("PAL_LEAN_STORE", "0")
+    old = Engine(engine.device)
+    try:
+        for name, fr in cases.items():
+            for med in (0.05, None):
+                for method in ("median", "adaptive"):
+                    lean.profile_begin()
+                    ta, ca = lean.gcc_phat_all_pairs(fr, fs, 1, method, 1.0, med, want_corr=True)
+                    lean.profile_end()
+                    assert "k_pfa_cols_lean" in lean.profile_entries(), sorted(lean.profile_entries())
+                    tb, cb = old.gcc_phat_all_pairs(fr, fs, 1, method, 1.0, med, want_corr=True)
+                    tag = (name, med, method)
+                    assert np.allclose(ca, cb, rtol=0, atol=4e-15), tag
+                    for f in ("k_sel", "branch", "k_argmax", "n_sel"):
+                        assert np.array_equal(ta[f], tb[f]), (tag, f)
+                    for f in ("cmax", "cmin", "snr", "sel_height"):
+                        assert np.allclose(ta[f], tb[f], rtol=1e-11, atol=1e-300), (tag, f)
+    finally:
+        lean.close()
+        old.close()
+
+
 def test_fused_column_pass_plateaus_and_grid_edges(engine, monkeypatch):
     """Samples with equal neighbours and peaks in the grid's first / last column (lags m = 0 or N2 - 1 mod N2) take the
     finish launch's own tests: quantised inputs give exact ties, and the window is the whole row."""
