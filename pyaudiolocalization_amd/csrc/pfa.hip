@@ -371,11 +371,10 @@ int Engine::pfa_pair_group_fused(const Plan& pl, const cd* permuted, const int4*
 }
 
 
-// ---- the column pass that finishes the rows itself (pfa_cols_fin.h): no correlation rows in HBM, no finish launch ----
-// One peak per row (main.py:204), the caller does not ask for `corr`, the column DFT has two to four chunks of output indices
-// (25 <= N1 <= 89) and the grid's rows have at least 256 columns.  Short column DFTs (one chunk, N1 <= 23: four strips per
-// block) keep the stored-row pass unless PAL_FIN_STRIPS=1: a lane then holds only N1 samples per row, and the exchange between
-// the blocks and the serial finish cost more than the stores and the finish launch they replace (C3: 0.95 against 1.11 M pairs/s).
+// ---- the column pass that finishes the rows itself (pfa_cols_fin.h, pfa_fin_lean.h): no correlation rows in HBM, no finish launch ----
+// One peak per row (main.py:204), the caller does not ask for `corr`, and the grid's rows have at least 256 columns.  Which column
+// forms take it is decided by measurement over the sync-padded lengths (see below); the other plans keep their rows in HBM - with
+// the same per-wavefront statistics where the grid is large enough (pfa_can_lean_store), else with round 2's statistics.
 bool Engine::pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const {
   const Pfa& f = pl.pfa;
   const bool strips = fin_strips;

@@ -6,6 +6,10 @@
 // neighbourhoods of the candidates it resolves.  Here everything the selection of ONE peak per row (num_peaks = 1,
 // main.py:204) can need is taken from the samples while they are in the accumulators:
 //
+// Two bodies share this kernel.  Without histograms (threshold 'adaptive', or 'median' with a multiplier in 0 .. 2: the default of
+// main.py:204) every WAVEFRONT runs the statistics of pfa_fin_lean.h on its own and one wavefront per transform finishes the rows:
+// that is the path of the metric run, read that header first.  With histograms (multipliers above 2) the block-level body below runs:
+//
 //   phase 1   as in k_pfa_cols_stats: histogram window of |x| around the block's median, maximum / first argmax, minimum,
 //             sums, highest strict peak, reported ties - plus, when the lag window max_expected_delay is set, the highest
 //             strict peak inside the window (it is kept by the distance rule unless a higher peak lies just outside the
