@@ -559,8 +559,13 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
                    (pfa ? pfa_sub == 0 && pfa_can_finish(pl, prm) : fourstep_can_finish(pl, prm));
   // stored rows + per-wavefront statistics (pfa_fin_lean.h with FinArgs.corr): the caller wants corr, or the plan has no finishing form
   const bool lean = !fin && pfa && table && !split && !ksel_multi && pfa_sub == 0 && pfa_can_lean_store(pl, prm);
+  // rows of any other route: their statistics in one launch over the stored rows (k_rows_lean)
+  // (calls of at least 200 000 pairs: the end-of-call count and the flagged rows' second pass - 1.8 % of the rows at C5's lag window -
+  //  cost the 30 000 - 80 000-pair calls of the stream chain more than the launch saves, and stall its host: 480 - 497 against 527 - 535 frames/s)
+  const bool rlean = !fin && !lean && table && !split && !ksel_multi && npairs >= 200000 && rows_can_lean(pl, prm) &&
+                     !(pfa && pfa_sub == 0 && pfa_can_fuse(pl));
   int* need = nullptr;
-  if (fin || lean) {
+  if (fin || lean || rlean) {
     void* np = nullptr;
     PAL_TRY(scratch(19, (size_t(2 * npairs) + 64) * sizeof(int), &np));     // [flags | list | count]
     need = static_cast<int*>(np);
@@ -624,7 +629,9 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
       PAL_HIP(hipStreamWaitEvent(stream2, ev_corr[slot], 0));
       pon = stream2;
     }
-    if (table && !fused && !fin && !lean)
+    if (rlean)
+      PAL_TRY(rows_lean_group(pl, crow, stride, G, rows, prm, n2, table + p0, need + p0, slot, pon));
+    else if (table && !fused && !fin && !lean)
       PAL_TRY(peaks(crow, stride, rows, n, n2, prm, table + p0, ksel_multi ? ksel_multi + p0 * PAL_MAX_PEAKS : nullptr, pon));
     if (split) PAL_HIP(hipEventRecord(ev_peaks[slot], stream2));
     return PAL_OK;
@@ -653,7 +660,7 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
       PAL_HIP(hipStreamWaitEvent(stream, ev_join3, 0));
     }
   }
-  if (fin || lean) {
+  if (fin || lean || rlean) {
     // The pairs the finishing blocks flagged (a threshold comparison inside the median's interval, a tie, a window peak next to
     // the window's edge, ...) go through the stored-row path now, packed in pair order.  The count comes to the host: this
     // is the one synchronisation of the call (its launch groups above never waited for the host).

@@ -97,6 +97,7 @@ struct Engine {
   bool fin_four = false;           // PAL_FIN_FOUR=1: on the four-step last pass
   bool fin_wide = false;           // PAL_FIN_WIDE=1: on column DFTs of five or six chunks
   bool fin_hist = false;           // PAL_FIN_HIST=1: histogram windows for every threshold multiplier
+  bool rows_lean = true;           // PAL_ROWS_LEAN=0: stored rows of the other routes keep the three statistics launches
   bool lean_store = true;          // PAL_LEAN_STORE=0: stored rows keep the round-2 statistics (pfa_cols_stats.h / three launches) + k_peak_finish
   int debug_memo = 0;              // PAL_DEBUG_MEMO=<n>: shrinks the distance rule's on-chip memo / stack (tests of its slow path)
   hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams
@@ -193,6 +194,9 @@ struct Engine {
   int fourstep_pair_group_fin(const Plan& pl, const cd* W, int G, int rows, const int* zero_rows, const pal_phat_params& prm, int n2,
                               pal_pair_record* table, int* need, int slot, hipStream_t on);
   bool pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const;   // pfa_cols_fin.h applies (one peak per row, N1 of 2..4 chunks)
+  bool rows_can_lean(const Plan& pl, const pal_phat_params& prm) const;        // k_rows_lean instead of pivots + stream + finish
+  int rows_lean_group(const Plan& pl, const double* corr, size_t stride, int G, int rows, const pal_phat_params& prm, int n2,
+                      pal_pair_record* table, int* need, int slot, hipStream_t on);
   bool pfa_can_lean_store(const Plan& pl, const pal_phat_params& prm) const;   // the per-wavefront statistics beside STORED rows (pfa_fin_lean.h)
   int pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* quads, int G, int rows, cd* Y, const int* zero_rows,
                          const pal_phat_params& prm, int n2, pal_pair_record* table, int* need, int slot, hipStream_t on,

@@ -284,6 +284,8 @@ int pal_create(int device, pal_handle* out) {
   env = getenv("PAL_FIN_WIDE");
   e->fin_wide = env && atoi(env) != 0;
   e->fin_hist = getenv("PAL_FIN_HIST") != nullptr;
+  env = getenv("PAL_ROWS_LEAN");
+  if (env) e->rows_lean = atoi(env) != 0;
   env = getenv("PAL_LEAN_STORE");
   if (env) e->lean_store = atoi(env) != 0;
   env = getenv("PAL_DEBUG_MEMO");

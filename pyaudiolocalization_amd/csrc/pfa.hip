@@ -383,6 +383,11 @@ bool Engine::pfa_can_finish(const Plan& pl, const pal_phat_params& prm) const {
   // and with short columns beside row tiles of up to 8192 points (+8 %); three chunks leave the fourth wavefront idle (-2 %), and
   // beside the 16384-point row tiles it is a wash
   bool cols_ok = f.r89 != nullptr || (f.nch >= 2 && f.nch <= 4) || (f.nch <= 1 && f.lm <= 13);
+  // ... on grids of at least twelve column blocks per transform (N2 >= 683; strips: N2 >= 2729): with fewer, a launch group is one or
+  // two rounds of blocks and the pass is the sum of one block's latencies - the stream chain's lengths (n = 24 000 ... 24 500:
+  // 59 x 407, seven blocks) ran 534 frames/s with the pass and 579 without
+  const int nblk = (f.n2 + (f.nch <= 1 ? 4 : 1) * kColsOwn - 1) / ((f.nch <= 1 ? 4 : 1) * kColsOwn);
+  if (!f.r89 && nblk < 12) cols_ok = false;
   if (fin_dense >= 0) cols_ok = f.r89 != nullptr || fin_dense != 0;      // PAL_FIN_DENSE=1 / 0: every / no dense column DFT
   if (f.nch <= 1 && strips) cols_ok = true;
   // five and six chunks (N1 up to 133: C5's 103 x 233; five- / six-wavefront blocks, no histogram form): opt-in, PAL_FIN_WIDE=1.
@@ -451,6 +456,7 @@ int Engine::fin_setup(const Plan& pl, int rows, int nblk, int grid_rows, int gri
   fa.pw = 1;
   fa.corr = nullptr;
   fa.stride = 0;
+  fa.store_rows = 0;
   fa.windowed = std::isnan(prm.max_expected_delay) ? 0 : 1;
   fa.win_lo = 1;
   fa.win_hi = n - 2;
@@ -516,6 +522,34 @@ int Engine::fourstep_pair_group_fin(const Plan& pl, const cd* W, int G, int rows
   return PAL_OK;
 }
 
+// Statistics of rows that are already in HBM, any route (k_rows_lean): one launch instead of pivots + stream + finish where one peak per
+// row is asked for and the threshold needs no histograms; flagged rows are resolved at the end of the call.
+bool Engine::rows_can_lean(const Plan& pl, const pal_phat_params& prm) const {
+  const bool nohist = prm.threshold_method > 0 || (prm.threshold_multiplier >= 0 && prm.threshold_multiplier <= 2.0 && !fin_hist);
+  // Measured: rows of 12 013 ... 24 013 samples +2 ... +8 % (C5 2.58 -> 2.87 M pairs/s: 66 us per group against 18 + 31 + 32), rows of
+  // 88 201 ... 88 367 -3 ... +1 %, C4's 191 999 the same: long rows keep the three launches (their stream pass runs at the HBM rate)
+  return rows_lean && fin_cols && prm.num_peaks == 1 && nohist && pl.nout == pl.n && pl.n >= 4096 && pl.n <= 50000;
+}
+
+int Engine::rows_lean_group(const Plan& pl, const double* corr, size_t stride, int G, int rows, const pal_phat_params& prm, int n2,
+                            pal_pair_record* table, int* need, int slot, hipStream_t on) {
+  constexpr int NS = 22;
+  const int chunks = (pl.n + kColsOwn - 1) / kColsOwn;
+  const int nblk = (chunks + 4 * NS - 1) / (4 * NS);
+  PeakArgs a;
+  FinArgs fa;
+  unsigned nwg = 0;
+  PAL_TRY(fin_setup(pl, rows, nblk, 1, kColsOwn, prm, n2, table, need, slot, on, a, fa, nwg, G));
+  fa.pw = 4;
+  fa.corr = const_cast<double*>(corr);
+  fa.stride = stride;
+  fa.store_rows = 0;
+  ProfScope ps(this, "k_rows_lean", on);
+  k_rows_lean<NS><<<dim3(nwg), dim3(256), 0, on>>>(corr, stride, G, nblk, a, fa, rows);
+  PAL_HIP(hipGetLastError());
+  return PAL_OK;
+}
+
 // The same pass with the correlation rows stored as well (the caller wants them, or the plan has no finishing form that pays):
 // per-wavefront statistics, no sibling polls, the finisher reads the SNR window from the stored row; flagged rows are resolved at the
 // end of the call like the finishing pass's.  Replaces pfa_cols_stats.h / the three statistics launches + k_peak_finish where one
@@ -543,6 +577,7 @@ int Engine::pfa_pair_group_fin(const Plan& pl, const cd* permuted, const int4* q
   PAL_TRY(fin_setup(pl, rows, nblk, f.n1, f.n2, prm, n2, table, need, slot, on, a, fa, nwg, G));
   fa.corr = corr;
   fa.stride = stride;
+  fa.store_rows = corr ? 1 : 0;
   static const bool want_stamps = getenv("PAL_DEBUG_STAMPS") != nullptr;
   PAL_TRY(pfa_rows(pl, permuted, quads, G, Y, on));
   {

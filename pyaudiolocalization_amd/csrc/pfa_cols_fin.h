@@ -69,6 +69,7 @@ struct FinArgs {
   int pw;                         // FinPartial entries and `done` words per column block: 1, or one per wavefront (pfa_fin_lean.h)
   double* corr;                   // null, or [rows][stride]: the pass ALSO stores the correlation rows (the caller wants them, or the plan
   size_t stride;                  //   has no finishing form): nobody polls siblings then, the finisher reads the SNR window from the stored row
+  int store_rows;                 // 1: this pass writes the rows (column forms); 0 with corr set: they are there already (k_rows_lean reads them)
   int cheb;                       // 1: no histograms - the median of |corr| is bounded by sqrt(2 mean(corr^2)) (see fin_row)
   unsigned long long* stamps;     // diagnostics (PAL_DEBUG_STAMPS=1): [workgroup][8] 100 MHz clock reads of lane 0 per phase
 };
@@ -915,6 +916,72 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE ==
   for (int r = 0; r < 2; ++r)
     if (2 * g + r < rows) fin_row<LANES>(pa, fa, 2 * g + r, N1, N2, nact, fsh, tid);
   stamp();                                                     // 6: both rows finished (last block only)
+}
+
+
+// ---- per-wavefront statistics over rows that are already in HBM (any route: the four-step last pass, column DFTs of five or six
+//      chunks, small grids): the counterpart of k_peak_pivots + k_peak_stream + k_peak_finish for one peak per row without histograms.
+// A wavefront reads NS overlapping chunks of 64 consecutive samples of both rows of a transform - chunk t = samples 62 t - 1 ...
+// 62 t + 62: lanes 1 .. 62 own a sample, lanes 0 and 63 hold the neighbours - which is the (slot, lane) layout of pfa_fin_lean.h with
+// N2 = 62 columns, m = 62 t + (lane - 1): the row's partial last chunk is the PART slot, chunks behind it do not exist.  No sibling
+// polls (FinArgs.corr set, store_rows 0); the finishing wavefront of the transform reads the SNR window from the row.
+template <int NS>
+__global__ __launch_bounds__(256) void k_rows_lean(const double* __restrict__ corr, size_t stride, int G, int nblk, PeakArgs pa, FinArgs fa, int rows) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xs = int(blockIdx.x & 7u), slot = int(blockIdx.x >> 3);
+  const int cb = slot % nblk, g = xs + 8 * (slot / nblk);
+  if (g >= G) return;                                          // (uniform)
+  int stamp_at = 0;
+  auto stamp = [&]() {
+    if (fa.stamps && tid == 0) fa.stamps[size_t(blockIdx.x) * 8 + stamp_at] = __builtin_amdgcn_s_memrealtime();
+    ++stamp_at;
+  };
+  stamp();
+  constexpr int W = kColsOwn;                                  // 62 owned samples per chunk
+  const int n = pa.n;
+  const int t0 = (cb * 4 + wave) * NS;                         // first chunk of this wavefront
+  const double* const r0 = corr + size_t(2 * g) * stride;
+  const double* const r1 = 2 * g + 1 < rows ? r0 + stride : r0;
+  const double keep1 = 2 * g + 1 < rows ? 1.0 : 0.0;
+  cd ro[NS];
+  unsigned emask = 0;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int m = W * (t0 + i) + lane - 1;
+    const bool ok = m >= 0 && m < n;
+    const int mc = ok ? m : 0;
+    const double a = r0[mc], b = r1[mc];
+    ro[i] = mk(ok ? a : 0.0, ok ? b * keep1 : 0.0);
+    if (W * (t0 + i) < n) emask |= 1u << (1 + i);
+  }
+  stamp();                                                     // 1: loaded
+  const int tp = (n - 1) / W;                                  // the row ends inside chunk tp
+  const int pslot = tp >= t0 && tp < t0 + NS ? 1 + tp - t0 : -1;
+  const bool own = lane >= 1 && lane <= W;
+  const bool pvalid = W * tp + lane - 1 < n;
+  const int st = t0 + (lane < NS ? lane : 0);
+  const bool last = fin_lean_r89<false, true, NS>(ro, mk(0, 0), st, emask, wave, lane, g, cb, nblk, 0, W, rows, 0, lane - 1, own, own, false, pslot,
+                                                  pvalid, pa, fa, stamp);
+  if (!last) return;
+  stamp();                                                     // 5
+  if (wave != 0) return;                                       // ONE wavefront finishes the transform's rows
+  bool late = false;
+  for (int q = lane; q < nblk * fa.pw; q += 64) {
+    int spins = 0;
+    while (ld_agent(fa.done + size_t(g) * nblk * fa.pw + q) != fa.epoch) {
+      if (++spins > kSpinLimit) { late = true; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  if (__ballot(late)) {
+    if (lane < 2 && 2 * g + lane < rows) { fa.need[2 * g + lane] = 1; atomicAdd(fa.status + 4, 1); atomicAdd(fa.status + 13, 1); }
+    return;
+  }
+#pragma nounroll
+  for (int r = 0; r < 2; ++r)
+    if (2 * g + r < rows) fin_row_wave(pa, fa, 2 * g + r, 0, W, lane);
+  stamp();                                                     // 6
 }
 
 }  // namespace pal

@@ -183,7 +183,7 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[NS], const cd c0, co
         const int cand = N2 * T(slot) + (c_lo - 1) + l;
         im = cand < im ? cand : im;
         nhit += __builtin_popcountll(mk);
-        vpeak = (innerm >> l & 1ull) && (!PART || cand <= n - 2) && readlane_d(x, l - 1) < V && readlane_d(x, l + 1) < V;
+        vpeak = (innerm >> l & 1ull) && (!PART || (cand >= 1 && cand <= n - 2)) && readlane_d(x, l - 1) < V && readlane_d(x, l + 1) < V;
       }
     });
     if (im == INT_MAX) im = -1;
@@ -207,7 +207,7 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[NS], const cd c0, co
           if (__ballot(x >= myfloor)) {
             const int m = m2 + N2 * T(slot);
             const double left = from_lower_lane(x), right = from_upper_lane(x);
-            const bool here = inner && (!PART || m <= n - 2);  // (four-step: the row ends inside the grid's last row)
+            const bool here = inner && (!PART || (m >= 1 && m <= n - 2));   // (the row's end points are never peaks; four-step / row chunks: the row ends inside a slot)
             const bool cand = here && x >= pfloor && (x > hb || (x == hb && m > mb));
             const bool pk = cand && left < x && right < x;
             hb = pk ? x : hb;
@@ -272,7 +272,7 @@ __device__ __forceinline__ bool fin_lean_r89(const cd (&ro)[NS], const cd c0, co
   // ---- stored-row form (FinArgs.corr): the samples go to HBM as well, and nothing below waits for a sibling - the finisher reads
   //      the SNR window around the row's maximum from the stored row
   const bool stored = fa.corr != nullptr;
-  if (stored) {
+  if (stored && fa.store_rows) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if (r >= nrow) continue;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of the stored-row column pass with per-wavefront statistics (PAL_LEAN_STORE=1, default) against the round-2 statistics
 (pfa_cols_stats.h / three launches + k_peak_finish; PAL_LEAN_STORE=0) on one box: every record field and, where asked for, the
-correlation rows.     python tools/check_lean.py [mics=6]"""
+correlation rows.     python tools/check_lean.py [mics=6] [PAL_LEAN_STORE | PAL_ROWS_LEAN]
+(PAL_ROWS_LEAN: k_rows_lean over the stored rows of the other routes against pivots + stream + finish.)"""
 import os
 import sys
 
@@ -11,8 +12,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("PAL_DEBUG_FALLBACK", "1")
 
 
+SWITCH = sys.argv[2] if len(sys.argv) > 2 else "PAL_LEAN_STORE"
+
+
 def engine(on):
-    os.environ["PAL_LEAN_STORE"] = "1" if on else "0"
+    os.environ[SWITCH] = "1" if on else "0"
     from pyaudiolocalization_amd import Engine
     return Engine(0)
 
@@ -22,7 +26,10 @@ def main():
     a, b = engine(True), engine(False)
     rng = np.random.default_rng(17)
     bad = 0
-    for L, fs in ((12000, 48000.0), (24000, 48000.0), (48000, 48000.0), (44100, 44100.0), (44110, 44100.0), (11170, 16000.0), (3000, 16000.0)):
+    lengths = ((12000, 48000.0), (24000, 48000.0), (48000, 48000.0), (44100, 44100.0), (44110, 44100.0), (11170, 16000.0), (3000, 16000.0))
+    if SWITCH == "PAL_ROWS_LEAN":
+        lengths = ((12000, 48000.0), (44101, 44100.0), (44184, 44100.0), (12007, 16000.0), (6007, 16000.0), (2100, 8000.0), (30011, 44100.0))
+    for L, fs in lengths:
         info = a.plan_info(L)
         base = rng.standard_normal(L + 64)
         cases = {"noise": rng.standard_normal((2, mics, L)),
