@@ -12,7 +12,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03_c"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 path = os.path.join(root, "fp64_flops_per_pair.json")
 out = json.load(open(path))
-PIPE = ("k_pfa_rows", "k_pfa_cols", "k_peak_", "k_flag_", "PairLoader", "CorrStorer")
+PIPE = ("k_pfa_rows", "k_pfa_cols", "k_rows_lean", "k_peak_", "k_flag_", "PairLoader", "CorrStorer")
 for cfg in ("c2", "c3", "c4", "c5"):
     line = json.loads(open(os.path.join(root, f"{tag}_bench_{cfg}.json")).read().strip().splitlines()[-1])
     per_launch = line["roofline"]["pairs_per_launch"]
@@ -21,6 +21,10 @@ for cfg in ("c2", "c3", "c4", "c5"):
     names = [k for k in traffic if any(p in k for p in PIPE) and "hhat" not in k]
     if any("PairLoader" in k for k in names):                       # four-step pair pipeline: its row pass is the 8192-point convolution
         names += [k for k in traffic if k.startswith("k_rowsreg<13,conv>") or k.startswith("k_rows<") and "conv" in k]
+    if any(k.startswith(("k_rows_lean", "k_pfa_cols_fin")) for k in traffic):
+        # the statistics launches of round 2 appear only in the end-of-call pass over the flagged rows (a few small dispatches per call:
+        # their per-dispatch averages are not per launch group) - left out, as are the k_flag_* helpers
+        names = [k for k in names if not k.startswith(("k_peak_", "k_flag_", "k_pfa_cols_stats"))]
     names = sorted(set(names))
     out[cfg] = {
         "fp64_flops_per_pair": round(sum(flops.get(k, 0) for k in names) / per_launch),
