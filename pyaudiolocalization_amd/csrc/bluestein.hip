@@ -562,7 +562,7 @@ int Engine::pair_correlations(Plan& pl, const cd* spectra, int nspec, const int4
   // rows of any other route: their statistics in one launch over the stored rows (k_rows_lean)
   // (calls of at least 200 000 pairs: the end-of-call count and the flagged rows' second pass - 1.8 % of the rows at C5's lag window -
   //  cost the 30 000 - 80 000-pair calls of the stream chain more than the launch saves, and stall its host: 480 - 497 against 527 - 535 frames/s)
-  const bool rlean = !fin && !lean && table && !split && !ksel_multi && npairs >= 200000 && rows_can_lean(pl, prm) &&
+  const bool rlean = !fin && !lean && table && !split && !ksel_multi && npairs >= rows_lean_min && rows_can_lean(pl, prm) &&
                      !(pfa && pfa_sub == 0 && pfa_can_fuse(pl));
   int* need = nullptr;
   if (fin || lean || rlean) {

@@ -98,6 +98,7 @@ struct Engine {
   bool fin_wide = false;           // PAL_FIN_WIDE=1: on column DFTs of five or six chunks
   bool fin_hist = false;           // PAL_FIN_HIST=1: histogram windows for every threshold multiplier
   bool rows_lean = true;           // PAL_ROWS_LEAN=0: stored rows of the other routes keep the three statistics launches
+  long long rows_lean_min = 200000;   // PAL_ROWS_LEAN_MIN=<pairs>: smallest call that takes k_rows_lean (tests lower it)
   bool lean_store = true;          // PAL_LEAN_STORE=0: stored rows keep the round-2 statistics (pfa_cols_stats.h / three launches) + k_peak_finish
   int debug_memo = 0;              // PAL_DEBUG_MEMO=<n>: shrinks the distance rule's on-chip memo / stack (tests of its slow path)
   hipEvent_t ev_corr[2] = {}, ev_peaks[2] = {};   // hand-offs of the two correlation buffers between the streams

@@ -286,6 +286,8 @@ int pal_create(int device, pal_handle* out) {
   e->fin_hist = getenv("PAL_FIN_HIST") != nullptr;
   env = getenv("PAL_ROWS_LEAN");
   if (env) e->rows_lean = atoi(env) != 0;
+  env = getenv("PAL_ROWS_LEAN_MIN");
+  if (env && atoll(env) >= 1) e->rows_lean_min = atoll(env);
   env = getenv("PAL_LEAN_STORE");
   if (env) e->lean_store = atoi(env) != 0;
   env = getenv("PAL_DEBUG_MEMO");

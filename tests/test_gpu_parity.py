@@ -346,6 +346,45 @@ def test_stored_row_pass_with_wavefront_statistics_equals_round2_statistics(engi
         old.close()
 
 
+@pytest.mark.parametrize("length,fs", [(12000, 48000.0), (6007, 16000.0), (2500, 8000.0)], ids=["pfa-103x233", "four-step-12013", "four-step-4999"])
+def test_row_major_statistics_pass_equals_the_three_launches(engine, length, fs, monkeypatch):
+    """k_rows_lean (per-wavefront statistics over rows already in HBM: 22 overlapping 64-sample chunks per wavefront, the row's last
+    chunk partial) against k_peak_pivots + k_peak_stream + k_peak_finish.  The engine takes it for calls of 200 000 pairs or more;
+    PAL_ROWS_LEAN_MIN=1 lets a small call through."""
+    from pyaudiolocalization_amd import Engine
+    rng = np.random.default_rng(length + 2)
+    mics = 6
+    base = rng.standard_normal(length + 64)
+    cases = {"noise": rng.standard_normal((2, mics, length)),
+             "delayed": (np.stack([base[d:d + length] for d in rng.integers(0, 64, mics)]) + 0.3 * rng.standard_normal((mics, length)))[None],
+             "tone": (np.sin(0.05 * np.arange(length))[None, :] + 0.3 * rng.standard_normal((mics, length)))[None]}
+    silent = rng.standard_normal((1, mics, length))
+    silent[0, 2] = 0.0
+    cases["silent"] = silent
+    monkeypatch.setenv("PAL_ROWS_LEAN_MIN", "1")
+    monkeypatch.setenv("PAL_ROWS_LEAN", "1")
+    lean = Engine(engine.device)
+    monkeypatch.setenv("PAL_ROWS_LEAN", "0")
+    old = Engine(engine.device)
+    try:
+        for name, fr in cases.items():
+            for med in (0.05, None, 0.001):
+                for method, mult in (("median", 1.0), ("adaptive", 1.0), ("median", 2.0)):
+                    lean.profile_begin()
+                    ta = lean.gcc_phat_all_pairs(fr, fs, 1, method, mult, med)
+                    lean.profile_end()
+                    assert "k_rows_lean" in lean.profile_entries(), sorted(lean.profile_entries())
+                    tb = old.gcc_phat_all_pairs(fr, fs, 1, method, mult, med)
+                    tag = (name, med, method, mult)
+                    for f in ("k_sel", "branch", "k_argmax", "n_sel"):
+                        assert np.array_equal(ta[f], tb[f]), (tag, f)
+                    for f in ("cmax", "cmin", "snr", "sel_height"):
+                        assert np.allclose(ta[f], tb[f], rtol=1e-11, atol=1e-300), (tag, f)
+    finally:
+        lean.close()
+        old.close()
+
+
 def test_fused_column_pass_plateaus_and_grid_edges(engine, monkeypatch):
     """Samples with equal neighbours and peaks in the grid's first / last column (lags m = 0 or N2 - 1 mod N2) take the
     finish launch's own tests: quantised inputs give exact ties, and the window is the whole row."""

@@ -17,6 +17,7 @@ SWITCH = sys.argv[2] if len(sys.argv) > 2 else "PAL_LEAN_STORE"
 
 def engine(on):
     os.environ[SWITCH] = "1" if on else "0"
+    os.environ["PAL_ROWS_LEAN_MIN"] = "1"                          # (k_rows_lean also for these small calls)
     from pyaudiolocalization_amd import Engine
     return Engine(0)
 
