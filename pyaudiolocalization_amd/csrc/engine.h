@@ -148,6 +148,11 @@ struct Engine {
   // device copy of the (trial, i<j) pair table of the last all-pairs shape
   void* quads = nullptr;
   int quad_B = 0, quad_M = 0;
+  // pair blocking (large arrays): pairs processed in 16 x 16 blocks of microphones, records scattered back to row-major order
+  int4* quads_blk = nullptr;
+  int* perm_blk = nullptr;
+  int blk_B = 0, blk_M = 0;
+  int pair_block = 16;             // PAL_PAIR_BLOCK=<microphones per block side>, 0 = off; used from 96 microphones up
 
   int fail(int code, const char* fmt, ...);
   int check(hipError_t e, const char* what);

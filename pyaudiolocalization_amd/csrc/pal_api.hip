@@ -163,6 +163,32 @@ static void build_quads(int B, int M, std::vector<int4>& q) {
       }
 }
 
+// The same pairs in blocks of `blk` x `blk` microphones (block rows I <= J; inside a block i ascending, j ascending): a launch group
+// of 480 pairs then touches some 64 spectra instead of 480 (C4: 256 microphones - every pair of one row i brings its own spectrum j,
+// 3 MB each).  perm[k] = row-major index of the pair processed k-th; the records are scattered back behind the call.
+static void build_quads_blocked(int B, int M, int blk, std::vector<int4>& q, std::vector<int>& perm) {
+  const int64_t P = int64_t(M) * (M - 1) / 2, np = P * B;
+  q.assign(size_t((np + 1) / 2), make_int4(0, 0, -1, -1));
+  perm.resize(size_t(np));
+  int64_t k = 0;
+  for (int b = 0; b < B; ++b)
+    for (int I = 0; I < M; I += blk)
+      for (int J = I; J < M; J += blk)
+        for (int i = I; i < I + blk && i < M; ++i)
+          for (int j = (J > i ? J : i + 1); j < J + blk && j < M; ++j, ++k) {
+            int4& t = q[size_t(k / 2)];
+            if (k & 1) { t.z = b * M + i; t.w = b * M + j; }
+            else { t.x = b * M + i; t.y = b * M + j; }
+            perm[size_t(k)] = int(int64_t(b) * P + int64_t(i) * M - int64_t(i) * (i + 1) / 2 + (j - i - 1));
+          }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_records(const pal_pair_record* __restrict__ src, const int* __restrict__ perm, int64_t n,
+                                                         pal_pair_record* __restrict__ dst) {
+  const int64_t k = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (k < n) dst[perm[k]] = src[k];
+}
+
 static int all_pairs_dev(Engine* e, const double* d_frames, int B, int M, int L, const pal_phat_params* prm,
                          pal_pair_record* d_table, double* d_corr) {
   PAL_TRY(validate(e, prm));
@@ -179,6 +205,29 @@ static int all_pairs_dev(Engine* e, const double* d_frames, int B, int M, int L,
   PAL_TRY(e->forward_spectra(*pl, d_frames, size_t(L), rows, L, spectra, nonzero));
   // the pair table depends on (B, M) only: keep it on the device between calls of the same shape
   const size_t nquads = size_t((int64_t(B) * M * (M - 1) / 2 + 1) / 2);
+  if (e->pair_block > 1 && M >= 96 && !d_corr && int64_t(B) * M * (M - 1) / 2 < INT32_MAX) {
+    const int64_t np = int64_t(B) * M * (M - 1) / 2;
+    if (e->blk_B != B || e->blk_M != M || !e->quads_blk) {
+      std::vector<int4> quads;
+      std::vector<int> perm;
+      build_quads_blocked(B, M, e->pair_block, quads, perm);
+      PAL_TRY(e->check(hipStreamSynchronize(e->stream), "stream sync"));
+      if (e->quads_blk) { (void)hipFree(e->quads_blk); e->quads_blk = nullptr; }
+      if (e->perm_blk) { (void)hipFree(e->perm_blk); e->perm_blk = nullptr; }
+      PAL_TRY(e->check(hipMalloc(&e->quads_blk, nquads * sizeof(int4)), "quads alloc"));
+      PAL_TRY(e->check(hipMalloc(&e->perm_blk, size_t(np) * sizeof(int)), "pair order alloc"));
+      PAL_TRY(e->check(hipMemcpyAsync(e->quads_blk, quads.data(), nquads * sizeof(int4), hipMemcpyHostToDevice, e->stream), "quads"));
+      PAL_TRY(e->check(hipMemcpyAsync(e->perm_blk, perm.data(), size_t(np) * sizeof(int), hipMemcpyHostToDevice, e->stream), "pair order"));
+      PAL_TRY(e->check(hipStreamSynchronize(e->stream), "quads sync"));
+      e->blk_B = B;
+      e->blk_M = M;
+    }
+    void* tp = nullptr;
+    PAL_TRY(e->scratch(23, size_t(np) * sizeof(pal_pair_record), &tp));
+    PAL_TRY(e->pair_correlations(*pl, spectra, rows, e->quads_blk, np, L, *prm, static_cast<pal_pair_record*>(tp), nullptr, nullptr, nonzero));
+    k_scatter_records<<<dim3(unsigned((np + 255) / 256)), dim3(256), 0, e->stream>>>(static_cast<const pal_pair_record*>(tp), e->perm_blk, np, d_table);
+    return e->check(hipGetLastError(), "k_scatter_records");
+  }
   if (e->quad_B != B || e->quad_M != M || !e->quads) {
     std::vector<int4> quads;
     build_quads(B, M, quads);
@@ -286,6 +335,8 @@ int pal_create(int device, pal_handle* out) {
   e->fin_hist = getenv("PAL_FIN_HIST") != nullptr;
   env = getenv("PAL_ROWS_LEAN");
   if (env) e->rows_lean = atoi(env) != 0;
+  env = getenv("PAL_PAIR_BLOCK");
+  if (env) e->pair_block = atoi(env);
   env = getenv("PAL_ROWS_LEAN_MIN");
   if (env && atoll(env) >= 1) e->rows_lean_min = atoll(env);
   env = getenv("PAL_LEAN_STORE");
@@ -310,6 +361,8 @@ void pal_destroy(pal_handle h) {
   for (cd* p : e->stage_twc) if (p) hipFree(p);
   for (void* p : e->ws) if (p) hipFree(p);
   if (e->quads) hipFree(e->quads);
+  if (e->quads_blk) hipFree(e->quads_blk);
+  if (e->perm_blk) hipFree(e->perm_blk);
   for (hipEvent_t ev : e->ev_pool) hipEventDestroy(ev);
   for (int k = 0; k < 2; ++k) { hipEventDestroy(e->ev_corr[k]); hipEventDestroy(e->ev_peaks[k]); }
   hipStreamDestroy(e->stream2);

@@ -385,6 +385,36 @@ def test_row_major_statistics_pass_equals_the_three_launches(engine, length, fs,
         old.close()
 
 
+def test_pair_blocking_of_large_arrays_returns_the_row_major_table(engine, monkeypatch):
+    """From 96 microphones up the pairs are processed in 16 x 16 blocks of microphones (a launch group then re-uses its spectra,
+    csrc/pal_api.hip build_quads_blocked) and the records are scattered back: the table must be the row-major i < j table.  Another
+    pair shares each packed transform, so float fields may differ by the partner's rounding noise; the indices may not."""
+    from pyaudiolocalization_amd import Engine
+    rng = np.random.default_rng(4)
+    monkeypatch.setenv("PAL_PAIR_BLOCK", "16")
+    blocked = Engine(engine.device)
+    monkeypatch.setenv("PAL_PAIR_BLOCK", "0")
+    plain = Engine(engine.device)
+    try:
+        for mics, length, frames in ((100, 3000, 2), (97, 2047, 1)):
+            fr = rng.standard_normal((frames, mics, length))
+            fr[0, 5] = 0.0                                          # a silent microphone
+            for med in (0.05, None):
+                ta = blocked.gcc_phat_all_pairs(fr, 16000.0, 1, "median", 1.0, med)
+                tb = plain.gcc_phat_all_pairs(fr, 16000.0, 1, "median", 1.0, med)
+                assert ta.shape == tb.shape == (frames, mics * (mics - 1) // 2)
+                for f in ("k_sel", "branch", "k_argmax", "n_sel"):
+                    assert np.array_equal(ta[f], tb[f]), (mics, med, f)
+                for f in ("cmax", "cmin", "snr", "sel_height"):
+                    assert np.allclose(ta[f], tb[f], rtol=1e-10, atol=1e-15), (mics, med, f)
+        want = O.all_pairs(fr[0][:12], 16000.0, max_expected_delay=None)   # (and against the oracle: the first 12 microphones' pairs)
+        got = blocked.gcc_phat_all_pairs(fr[:, :12], 16000.0, 1, "median", 1.0, None)[0]
+        assert np.array_equal(got["k_sel"], want["k_sel"])
+    finally:
+        blocked.close()
+        plain.close()
+
+
 def test_fused_column_pass_plateaus_and_grid_edges(engine, monkeypatch):
     """Samples with equal neighbours and peaks in the grid's first / last column (lags m = 0 or N2 - 1 mod N2) take the
     finish launch's own tests: quantised inputs give exact ties, and the window is the whole row."""
